@@ -1,0 +1,144 @@
+/*
+ * smplraster.h - C ABI of libsmplraster_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the SMPL decoder + orthographic projection + visibility mask +
+ * 31-part / silhouette soft-rasteriser of akashsengupta1997/indirect_learning_pose-shape.
+ * The reference has no FFI: the path is a composition of TensorFlow ops inside Keras
+ * Layer/Lambda callables.  Each entry point below replaces the TF graph of one of those
+ * callables (cited as file:line of the reference) and is what a binding for that callable
+ * would call.  The Python host side (`indirect_learning_pose-shape_amd/keras_smpl/ modules`)
+ * binds them with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous row-major fp32 / int32 / int16 data,
+ *    owned by the caller for the duration of the launch (the library allocates nothing);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); launches are
+ *    asynchronous, never synchronise and are HIP-graph capturable;
+ *  - return value: 0 on success, a positive hipError_t if a launch failed, or a negative
+ *    SMPLR_E* code for an argument error; `smplr_last_error()` describes the last failure
+ *    on the calling thread;
+ *  - B = meshes in the batch, V = vertices (6890), VP = ceil(V / vertex_sampling) projected
+ *    vertices, W = raster width/height, P = body parts (31), J = 24 joints.
+ */
+#ifndef SMPLRASTER_H
+#define SMPLRASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMPLR_ABI_VERSION 1
+#define SMPLR_NJ 24            /* joints                                   */
+#define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
+#define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
+
+#define SMPLR_EINVAL (-1)      /* bad size / null pointer                  */
+#define SMPLR_EUNSUPPORTED (-2)
+
+int smplr_abi_version(void);
+const char *smplr_last_error(void);
+
+/* ---- SMPLLayer.call: keras_smpl/batch_smpl.py:96-153 --------------------------------- */
+
+/* Rodrigues (batch_smpl.py:255-276, 230-253), pose feature (:122), joints from betas
+ * (J = J_template + J_dirs * beta, algebraically :106-115) and the 24-joint kinematic chain
+ * (batch_global_rigid_transformation, :168-228).
+ *   x     (B, x_stride)  rows [cam(num_cam) | theta(72) | beta(10)]
+ *   coef  (B, 220)       [beta(10) | pose_feature(207) | 0,0,0]  - the blend GEMM's A operand
+ *   Rs    (B,24,9)  J (B,24,3)  A (B,24,12) = rows 0..2 of the reference's (4,4) A
+ *   J_transformed (B,24,3)  (batch_smpl.py:131, :216)                                      */
+int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B,
+                   const float *J_template, const float *J_dirs, const int32_t *parents,
+                   float *coef, float *Rs, float *J, float *A, float *J_transformed,
+                   void *stream);
+
+/* Backward of the above.  dcoef (B,220), dA (B,24,12), dJ_transformed (B,24,3) or NULL.
+ * Writes dx (B, x_stride) columns [num_cam, num_cam+82); camera columns are zeroed.        */
+int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B,
+                   const float *J_dirs, const int32_t *parents,
+                   const float *Rs, const float *J, const float *A,
+                   const float *dcoef, const float *dA, const float *dJ_transformed,
+                   float *dx, void *stream);
+
+/* Blend shapes (batch_smpl.py:106-108 and :126-128 as ONE fp32-MFMA GEMM):
+ *   v_posed (B,N3) = coef (B,220) x blend (220,N3) + v_template (N3),  N3 = 3*V.
+ * blend rows 0..9 = shapedirs, 10..216 = posedirs, 217..219 = 0.                            */
+int smplr_blend_fwd(const float *coef, const float *blend, const float *v_template,
+                    int B, int N3, float *v_posed, void *stream);
+
+/* dcoef (B,220) = dv_posed (B,N3) x blend^T.  workspace: smplr_blend_bwd_workspace(B) bytes. */
+size_t smplr_blend_bwd_workspace(int B, int N3);
+int smplr_blend_bwd(const float *dv_posed, const float *blend, int B, int N3,
+                    float *dcoef, void *workspace, void *stream);
+
+/* Linear-blend skinning (batch_smpl.py:135-145) with the orthographic projection
+ * (projection.py:54-81) as an optional epilogue.
+ *   verts (B,V,3) = (sum_j w[v][j] A[b][j]) . [v_posed;1]
+ *   proj  (B,VP,3) = (u0 + k_u x, v0 + k_v y, z) of vertices 0, vs, 2vs, ...  (NULL: skip)
+ *   cam = x (row stride x_stride; columns 0..3 = k_u,k_v,u0,v0), may be NULL iff proj NULL. */
+int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *A,
+                   const float *cam, int x_stride, int B, int V, int vertex_sampling,
+                   float *verts, float *proj, void *stream);
+
+/* Backward of skinning (+ projection epilogue).
+ *   dverts (B,V,3) or NULL;  dproj (B,VP,3) or NULL (the rasterisers write its z column as 0:
+ *   z only feeds the non-differentiable mask, compute_mask.py:30);  at least one is required.
+ *   dv_posed (B,V,3), dA (B,24,12) (overwritten), dcam (B,4) or NULL = d[k_u,k_v,u0,v0].
+ *   workspace: smplr_skin_bwd_workspace(B,V) bytes (per-block partials, summed in fixed order). */
+size_t smplr_skin_bwd_workspace(int B, int V);
+int smplr_skin_bwd(const float *dverts, const float *dproj,
+                   const float *v_posed, const float *lbs_weights, const float *A,
+                   const float *cam, int x_stride, int B, int V, int vertex_sampling,
+                   float *dv_posed, float *dA, float *dcam, void *workspace, void *stream);
+
+/* ---- orthographic_project: keras_smpl/projection.py:54-81 ------------------------------ */
+int smplr_project_fwd(const float *verts, const float *cam, int x_stride, int B, int V,
+                      int vertex_sampling, float *proj, void *stream);
+/* dverts (B,V,3) fully written (zeros at unsampled vertices), dcam (B,4).                   */
+int smplr_project_bwd(const float *dproj, const float *verts, const float *cam, int x_stride,
+                      int B, int V, int vertex_sampling, float *dverts, float *dcam,
+                      void *stream);
+
+/* ---- compute_mask: keras_smpl/compute_mask.py:12-108 (stateless semantics) ------------- */
+/* mask (B,VP) in {1,500}: 1 for the arg-max-z vertex of each occupied cell of a
+ * grid_wh x grid_wh grid of rounded (half-to-even) pixel positions, lowest index on ties;
+ * with ref_compat != 0 vertex 1 is also visible whenever a cell is empty (:99).            */
+int smplr_visibility(const float *proj, int B, int VP, int grid_wh, int ref_compat,
+                     float *mask, void *stream);
+
+/* ---- projects_to_seg: keras_smpl/projects_to_seg.py:9-69 -------------------------------- */
+/* Part table, built once on the host from part_vertices.pkl (projects_to_seg.py:18-24,36-37):
+ *   part_pos (KP) int32: positions into the VP-long vertex list, part-major, each part padded
+ *                        to a multiple of SMPLR_CHUNK with -1;
+ *   part_off (P+1) int32: padded offsets (multiples of SMPLR_CHUNK).
+ * sorted (B,KP,4) is scratch the call fills: (u, v, mask^2, mask) per slot.
+ * seg (B,W,W,P+1): channel 0 = 1 - clip(sum_p score_p, 0, 1); channel 1+p =
+ *   max_v exp(-mask_v * |proj_v - (c,r)|); rows flipped (:68).
+ * arg (B,W,W,32) int16: slots 0..P-1 = position (in the VP list) of the maximising vertex,
+ *   slot 31 = 1 iff 0 <= sum_p <= 1 (the clip's pass-through gate).  Requires P <= 31.      */
+int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W,
+                  const int32_t *part_pos, const int32_t *part_off, int P, int KP,
+                  float *sorted, float *seg, int16_t *arg, void *stream);
+
+/* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
+ * the first arg-min vertex only; it is 0 where the distance is 0 (TF: NaN).                 */
+int smplr_seg_bwd(const float *dseg, const float *seg, const int16_t *arg,
+                  const float *proj, const float *mask, int B, int VP, int W, int P,
+                  float *dproj, void *stream);
+
+/* ---- projects_to_silhouette: keras_smpl/projects_to_silhouette.py:14-44 ----------------- */
+/* silh (B,W,W,2) = [1-s, s], s = max_v exp(-|proj_v-(c,r)|/1.2) over ALL VP vertices, rows
+ * flipped; arg (B,W,W) int32 = maximising vertex.  workspace: smplr_silh_workspace(B,VP) B.  */
+size_t smplr_silh_workspace(int B, int VP);
+int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg,
+                   void *workspace, void *stream);
+int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg,
+                   const float *proj, int B, int VP, int W, float *dproj, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMPLRASTER_H */

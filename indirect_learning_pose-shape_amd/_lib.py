@@ -1,0 +1,93 @@
+"""ctypes binding of libsmplraster_hip.so (the C ABI declared in include/smplraster.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C indirect_learning_pose-shape_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmplraster_hip.so")
+
+KPAD = 220
+CHUNK = 8
+
+P = c_void_p
+I = c_int
+
+# name -> (restype, argtypes); mirrors include/smplraster.h one to one.
+SIGNATURES = {
+    "smplr_abi_version": (c_int, []),
+    "smplr_last_error": (c_char_p, []),
+    "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "smplr_pose_bwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "smplr_blend_fwd": (c_int, [P, P, P, I, I, P, P]),
+    "smplr_blend_bwd_workspace": (c_size_t, [I, I]),
+    "smplr_blend_bwd": (c_int, [P, P, I, I, P, P, P]),
+    "smplr_skin_fwd": (c_int, [P, P, P, P, I, I, I, I, P, P, P]),
+    "smplr_skin_bwd_workspace": (c_size_t, [I, I]),
+    "smplr_skin_bwd": (c_int, [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
+    "smplr_project_fwd": (c_int, [P, P, I, I, I, I, P, P]),
+    "smplr_project_bwd": (c_int, [P, P, P, I, I, I, I, P, P, P]),
+    "smplr_visibility": (c_int, [P, I, I, I, I, P, P]),
+    "smplr_seg_fwd": (c_int, [P, P, I, I, I, P, P, I, I, P, P, P, P]),
+    "smplr_seg_bwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P]),
+    "smplr_silh_workspace": (c_size_t, [I, I]),
+    "smplr_silh_fwd": (c_int, [P, I, I, I, P, P, P, P]),
+    "smplr_silh_bwd": (c_int, [P, P, P, P, I, I, I, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once) and bind every symbol of the header; fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "HIP extension missing: %s not found. Build it with "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, gfx950)." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.smplr_abi_version() != 1:
+        raise RuntimeError("libsmplraster_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().smplr_last_error().decode("utf-8", "replace")
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    """The HIP path only: fp32/int device tensors, contiguous.  No CPU fallback exists."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a HIP device (got %s); this framework has no CPU path"
+                           % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    return t.contiguous()

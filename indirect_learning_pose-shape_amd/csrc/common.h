@@ -1,0 +1,49 @@
+// Shared helpers for libsmplraster_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/smplraster.h"
+
+namespace smplr {
+
+void set_error(const char *fmt, ...);
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Argument check -> negative code + message; launch check -> positive hipError_t.
+#define SMPLR_REQUIRE(cond, ...)                       \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      ::smplr::set_error(__VA_ARGS__);                 \
+      return SMPLR_EINVAL;                             \
+    }                                                  \
+  } while (0)
+
+#define SMPLR_LAUNCH_CHECK(name)                                              \
+  do {                                                                        \
+    hipError_t e__ = hipGetLastError();                                       \
+    if (e__ != hipSuccess) {                                                  \
+      ::smplr::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return (int)e__;                                                        \
+    }                                                                         \
+  } while (0)
+
+#define SMPLR_HIP(call)                                                       \
+  do {                                                                        \
+    hipError_t e__ = (call);                                                  \
+    if (e__ != hipSuccess) {                                                  \
+      ::smplr::set_error("%s failed: %s", #call, hipGetErrorString(e__));     \
+      return (int)e__;                                                        \
+    }                                                                         \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace smplr

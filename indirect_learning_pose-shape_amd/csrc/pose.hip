@@ -1,0 +1,287 @@
+// K1 pose kernels: Rodrigues + pose feature + joints-from-betas + 24-joint kinematic chain,
+// forward and backward.  One 64-lane wavefront per mesh, 4 meshes per workgroup; the chain's
+// 23 dependent 3x4 products run out of LDS with lanes = matrix elements.
+//
+// Reference: keras_smpl/batch_smpl.py:255-276 (batch_rodrigues), :230-253 (batch_skew),
+// :122 (pose_feature), :106-115 (J from v_shaped; here J = J_template + J_dirs*beta, which is
+// the same linear map evaluated in the other association order), :168-228 (global rigid).
+#include <stdarg.h>
+#include "common.h"
+
+namespace smplr {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+constexpr int MPB = 4;  // meshes (waves) per block
+
+struct PoseLds {
+  float Rs[24][9];
+  float J[24][3];
+  float G[24][12];   // rows 0..2 of the 4x4 world transform: [R | t]
+  float dGR[24][9];
+  float dGt[24][3];
+  float dJ[24][3];
+  float dR[24][9];
+};
+
+// R = cos*I + (1-cos)*r r^T + sin*skew(r),  angle = |theta + 1e-8|, r = theta/angle.
+__device__ __forceinline__ void rodrigues(const float t[3], float R[9]) {
+  const float e0 = t[0] + 1e-8f, e1 = t[1] + 1e-8f, e2 = t[2] + 1e-8f;
+  const float angle = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  const float rx = t[0] / angle, ry = t[1] / angle, rz = t[2] / angle;
+  float s, c;
+  sincosf(angle, &s, &c);
+  const float oc = 1.0f - c;
+  R[0] = c + oc * rx * rx;
+  R[1] = oc * rx * ry - s * rz;
+  R[2] = oc * rx * rz + s * ry;
+  R[3] = oc * ry * rx + s * rz;
+  R[4] = c + oc * ry * ry;
+  R[5] = oc * ry * rz - s * rx;
+  R[6] = oc * rz * rx - s * ry;
+  R[7] = oc * rz * ry + s * rx;
+  R[8] = c + oc * rz * rz;
+}
+
+// Given dR (gradient wrt the 9 entries of R) return dtheta.
+__device__ __forceinline__ void rodrigues_bwd(const float t[3], const float dR[9], float dt[3]) {
+  const float e[3] = {t[0] + 1e-8f, t[1] + 1e-8f, t[2] + 1e-8f};
+  const float angle = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const float inv = 1.0f / angle;
+  const float r[3] = {t[0] * inv, t[1] * inv, t[2] * inv};
+  float s, c;
+  sincosf(angle, &s, &c);
+  const float oc = 1.0f - c;
+  // d/d angle: -s*I + s*r r^T + c*K
+  const float tr = dR[0] + dR[4] + dR[8];
+  float rDr = 0.f;  // sum_ij dR_ij r_i r_j
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rDr += dR[i * 3 + j] * r[i] * r[j];
+  // sum_ij dR_ij K_ij with K = skew(r)
+  const float w0 = dR[7] - dR[5], w1 = dR[2] - dR[6], w2 = dR[3] - dR[1];
+  const float dK = w0 * r[0] + w1 * r[1] + w2 * r[2];
+  float da = -s * tr + s * rDr + c * dK;
+  // d/d r_k: (1-c) * ((dR r)_k + (dR^T r)_k) + s * w_k
+  float dr[3];
+  const float w[3] = {w0, w1, w2};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a += dR[k * 3 + j] * r[j] + dR[j * 3 + k] * r[j];
+    dr[k] = oc * a + s * w[k];
+  }
+  // r = t/angle  ->  dt += dr/angle ; dangle -= dr.t / angle^2
+  da -= (dr[0] * t[0] + dr[1] * t[1] + dr[2] * t[2]) * inv * inv;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dt[k] = dr[k] * inv + da * e[k] * inv;
+}
+
+__global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
+    const float *__restrict__ x, int x_stride, int num_cam, int B,
+    const float *__restrict__ J_template, const float *__restrict__ J_dirs,
+    const int *__restrict__ parents, float *__restrict__ coef, float *__restrict__ Rs_out,
+    float *__restrict__ J_out, float *__restrict__ A_out, float *__restrict__ newJ_out) {
+  __shared__ PoseLds lds[MPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * MPB + wave;
+  const bool live = n < B;
+  PoseLds &L = lds[wave];
+  const float *xr = x + (size_t)(live ? n : 0) * x_stride;
+  const float *beta = xr + num_cam + 72;
+
+  if (live) {
+    float *cf = coef + (size_t)n * SMPLR_KPAD;
+    if (lane < 24) {
+      float t[3] = {xr[num_cam + 3 * lane], xr[num_cam + 3 * lane + 1], xr[num_cam + 3 * lane + 2]};
+      float R[9];
+      rodrigues(t, R);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        L.Rs[lane][e] = R[e];
+        Rs_out[((size_t)n * 24 + lane) * 9 + e] = R[e];
+      }
+      if (lane >= 1) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          cf[10 + 9 * (lane - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+      }
+    }
+    if (lane < 10) cf[lane] = beta[lane];
+    if (lane >= 10 && lane < 13) cf[207 + lane] = 0.0f;  // 217..219
+    for (int e = lane; e < 72; e += 64) {
+      float acc = J_template[e];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) acc += J_dirs[e * 10 + k] * beta[k];
+      L.J[e / 3][e % 3] = acc;
+      J_out[(size_t)n * 72 + e] = acc;
+    }
+  }
+  __syncthreads();
+  // root
+  if (live && lane < 12) {
+    const int r = lane >> 2, c = lane & 3;
+    L.G[0][lane] = (c < 3) ? L.Rs[0][r * 3 + c] : L.J[0][r];
+  }
+  __syncthreads();
+  for (int i = 1; i < 24; ++i) {
+    const int p = parents[i];
+    if (live && lane < 12) {
+      const int r = lane >> 2, c = lane & 3;
+      float acc;
+      if (c < 3) {
+        acc = L.G[p][r * 4 + 0] * L.Rs[i][0 * 3 + c] + L.G[p][r * 4 + 1] * L.Rs[i][1 * 3 + c] +
+              L.G[p][r * 4 + 2] * L.Rs[i][2 * 3 + c];
+      } else {
+        acc = L.G[p][r * 4 + 0] * (L.J[i][0] - L.J[p][0]) + L.G[p][r * 4 + 1] * (L.J[i][1] - L.J[p][1]) +
+              L.G[p][r * 4 + 2] * (L.J[i][2] - L.J[p][2]) + L.G[p][r * 4 + 3];
+      }
+      L.G[i][lane] = acc;
+    }
+    __syncthreads();
+  }
+  if (live) {
+    for (int e = lane; e < 288; e += 64) {
+      const int j = e / 12, rc = e % 12, r = rc >> 2, c = rc & 3;
+      float v;
+      if (c < 3) {
+        v = L.G[j][rc];
+      } else {
+        v = L.G[j][r * 4 + 3] - (L.G[j][r * 4 + 0] * L.J[j][0] + L.G[j][r * 4 + 1] * L.J[j][1] +
+                                 L.G[j][r * 4 + 2] * L.J[j][2]);
+      }
+      A_out[(size_t)n * 288 + e] = v;
+    }
+    for (int e = lane; e < 72; e += 64) newJ_out[(size_t)n * 72 + e] = L.G[e / 3][(e % 3) * 4 + 3];
+  }
+}
+
+__global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
+    const float *__restrict__ x, int x_stride, int num_cam, int B,
+    const float *__restrict__ J_dirs, const int *__restrict__ parents,
+    const float *__restrict__ Rs_in, const float *__restrict__ J_in, const float *__restrict__ A_in,
+    const float *__restrict__ dcoef, const float *__restrict__ dA, const float *__restrict__ dnewJ,
+    float *__restrict__ dx) {
+  __shared__ PoseLds lds[MPB];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * MPB + wave;
+  const bool live = n < B;
+  PoseLds &L = lds[wave];
+  const size_t nn = live ? n : 0;
+
+  if (live) {
+    for (int e = lane; e < 216; e += 64) L.Rs[e / 9][e % 9] = Rs_in[nn * 216 + e];
+    for (int e = lane; e < 72; e += 64) L.J[e / 3][e % 3] = J_in[nn * 72 + e];
+    for (int e = lane; e < 288; e += 64) L.G[e / 12][e % 12] = A_in[nn * 288 + e];  // G.R = A.R
+  }
+  __syncthreads();
+  if (live && lane < 24) {
+    const int i = lane;
+    const float *dAi = dA + nn * 288 + i * 12;
+    float dAt[3] = {dAi[3], dAi[7], dAi[11]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) L.dGR[i][r * 3 + c] = dAi[r * 4 + c] - dAt[r] * L.J[i][c];
+      L.dGt[i][r] = dAt[r] + (dnewJ ? dnewJ[nn * 72 + i * 3 + r] : 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      L.dJ[i][c] = -(L.G[i][0 * 4 + c] * dAt[0] + L.G[i][1 * 4 + c] * dAt[1] + L.G[i][2 * 4 + c] * dAt[2]);
+  }
+  __syncthreads();
+  for (int i = 23; i >= 1; --i) {
+    const int p = parents[i];
+    float upd = 0.f;
+    if (live && lane < 9) {
+      const int r = lane / 3, c = lane % 3;
+      // dR_i = Gp.R^T dGR_i
+      L.dR[i][lane] = L.G[p][0 * 4 + r] * L.dGR[i][0 * 3 + c] + L.G[p][1 * 4 + r] * L.dGR[i][1 * 3 + c] +
+                      L.G[p][2 * 4 + r] * L.dGR[i][2 * 3 + c];
+      // dGR_p += dGR_i R_i^T + dGt_i (x) (J_i - J_p)
+      upd = L.dGR[i][r * 3 + 0] * L.Rs[i][c * 3 + 0] + L.dGR[i][r * 3 + 1] * L.Rs[i][c * 3 + 1] +
+            L.dGR[i][r * 3 + 2] * L.Rs[i][c * 3 + 2] + L.dGt[i][r] * (L.J[i][c] - L.J[p][c]);
+      L.dGR[p][lane] += upd;
+    } else if (live && lane >= 16 && lane < 19) {
+      const int c = lane - 16;
+      L.dGt[p][c] += L.dGt[i][c];
+      const float tmp = L.G[p][0 * 4 + c] * L.dGt[i][0] + L.G[p][1 * 4 + c] * L.dGt[i][1] +
+                        L.G[p][2 * 4 + c] * L.dGt[i][2];
+      L.dJ[i][c] += tmp;
+      L.dJ[p][c] -= tmp;
+    }
+    __syncthreads();
+  }
+  if (live && lane < 9) L.dR[0][lane] = L.dGR[0][lane];
+  if (live && lane >= 16 && lane < 19) L.dJ[0][lane - 16] += L.dGt[0][lane - 16];
+  __syncthreads();
+  if (live) {
+    float *dxr = dx + nn * x_stride;
+    const float *xr = x + nn * x_stride;
+    const float *dc = dcoef + nn * SMPLR_KPAD;
+    if (lane < 24) {
+      float g[9];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) g[e] = L.dR[lane][e] + (lane >= 1 ? dc[10 + 9 * (lane - 1) + e] : 0.0f);
+      float t[3] = {xr[num_cam + 3 * lane], xr[num_cam + 3 * lane + 1], xr[num_cam + 3 * lane + 2]};
+      float dt[3];
+      rodrigues_bwd(t, g, dt);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dxr[num_cam + 3 * lane + k] = dt[k];
+    } else if (lane >= 32 && lane < 42) {
+      const int k = lane - 32;
+      float acc = dc[k];
+      for (int e = 0; e < 72; ++e) acc += L.dJ[e / 3][e % 3] * J_dirs[e * 10 + k];
+      dxr[num_cam + 72 + k] = acc;
+    } else if (lane >= 48 && lane < 48 + num_cam) {
+      dxr[lane - 48] = 0.0f;
+    }
+  }
+}
+
+}  // namespace smplr
+
+extern "C" {
+
+int smplr_abi_version(void) { return SMPLR_ABI_VERSION; }
+const char *smplr_last_error(void) { return smplr::g_err; }
+
+int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B, const float *J_template,
+                   const float *J_dirs, const int32_t *parents, float *coef, float *Rs, float *J,
+                   float *A, float *J_transformed, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && num_cam >= 0 && num_cam <= 16 && x_stride >= num_cam + 82,
+                "smplr_pose_fwd: bad sizes B=%d num_cam=%d x_stride=%d", B, num_cam, x_stride);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(x && J_template && J_dirs && parents && coef && Rs && J && A && J_transformed,
+                "smplr_pose_fwd: null pointer");
+  hipLaunchKernelGGL(pose_fwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
+                     x, x_stride, num_cam, B, J_template, J_dirs, parents, coef, Rs, J, A, J_transformed);
+  SMPLR_LAUNCH_CHECK("smplr_pose_fwd");
+  return 0;
+}
+
+int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B, const float *J_dirs,
+                   const int32_t *parents, const float *Rs, const float *J, const float *A,
+                   const float *dcoef, const float *dA, const float *dJ_transformed, float *dx,
+                   void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && num_cam >= 0 && num_cam <= 16 && x_stride >= num_cam + 82,
+                "smplr_pose_bwd: bad sizes B=%d num_cam=%d x_stride=%d", B, num_cam, x_stride);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(x && J_dirs && parents && Rs && J && A && dcoef && dA && dx, "smplr_pose_bwd: null pointer");
+  hipLaunchKernelGGL(pose_bwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
+                     x, x_stride, num_cam, B, J_dirs, parents, Rs, J, A, dcoef, dA, dJ_transformed, dx);
+  SMPLR_LAUNCH_CHECK("smplr_pose_bwd");
+  return 0;
+}
+
+}  // extern "C"

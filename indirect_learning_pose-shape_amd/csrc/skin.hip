@@ -1,0 +1,312 @@
+// K3 linear-blend skinning (+ orthographic projection epilogue) and its backward, plus the
+// stand-alone projection op.
+//
+// Reference: keras_smpl/batch_smpl.py:135-145 (W tiled to (N,6890,24), T = W x A, v_homo =
+// T x [v_posed;1]) and keras_smpl/projection.py:54-81.  The reference materialises W (0.66 MB
+// per mesh) and T (0.44 MB per mesh); here a lane owns one vertex, keeps its 24 skinning
+// weights in registers across a group of meshes, and reads each mesh's 24x12 joint matrix
+// through wave-uniform (scalar) loads.
+//
+// Backward: dv_posed = T^T g per vertex on the VALU;  dA[j] = sum_v w[v][j] * (g (x) [v_posed;1])
+// is a (24 x Vchunk) x (Vchunk x 12) product per mesh and runs on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, two 16-joint tiles, K = 64 vertices per wave), reduced across the
+// block's waves in LDS and across blocks by a fixed-order second kernel (no atomics).
+#include "common.h"
+
+namespace smplr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK_MB = 4;       // meshes per thread in the forward (weights stay in registers)
+constexpr int SKB_T = 512;     // backward block: 512 vertices (8 waves)
+
+__global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__ v_posed,
+                                                       const float *__restrict__ lbs,
+                                                       const float *__restrict__ A,
+                                                       const float *__restrict__ cam, int x_stride,
+                                                       int B, int V, int vs, int VP,
+                                                       float *__restrict__ verts,
+                                                       float *__restrict__ proj) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  const bool live = v < V;
+  const int vc = live ? v : V - 1;
+  float w[24];
+  {
+    const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const float4 t = wp[q];
+      w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    }
+  }
+  const bool sampled = (vs <= 1) || (v % vs == 0);
+  const int vp_idx = (vs <= 1) ? v : v / vs;
+  for (int mi = 0; mi < SK_MB; ++mi) {
+    const int n = blockIdx.y * SK_MB + mi;   // wave-uniform
+    if (n >= B) break;
+    const float *An = A + (size_t)n * 288;
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 24; ++j)
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
+    const float *vp = v_posed + ((size_t)n * V + vc) * 3;
+    const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+    const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
+    const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
+    const float Z = T[8] * p0 + T[9] * p1 + T[10] * p2 + T[11];
+    if (live) {
+      if (verts) {
+        float *o = verts + ((size_t)n * V + v) * 3;
+        o[0] = X; o[1] = Y; o[2] = Z;
+      }
+      if (proj && sampled) {
+        const float *c = cam + (size_t)n * x_stride;
+        float *o = proj + ((size_t)n * VP + vp_idx) * 3;
+        o[0] = c[2] + X * c[0];
+        o[1] = c[3] + Y * c[1];
+        o[2] = Z;
+      }
+    }
+  }
+}
+
+// One block = one mesh x 512 vertices.  part layout per (mesh, block): 288 dA + 4 dcam floats.
+constexpr int SKB_PART = 292;
+
+__global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
+    const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
+    const float *__restrict__ lbs, const float *__restrict__ A, const float *__restrict__ cam,
+    int x_stride, int B, int V, int vs, int VP, float *__restrict__ dv_posed, float *__restrict__ part) {
+  __shared__ float sG[SKB_T][4];    // g (3) per vertex
+  __shared__ float sP[SKB_T][4];    // [v_posed;1]
+  __shared__ float sRed[SKB_T / 64][SKB_PART];
+  const int n = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int v = blockIdx.x * SKB_T + tid;
+  const bool live = v < V;
+  const int vc = live ? v : V - 1;
+  const float *An = A + (size_t)n * 288;
+
+  float w[24];
+  {
+    const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const float4 t = wp[q];
+      w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    }
+  }
+  float T[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 24; ++j)
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
+  const float *vp = v_posed + ((size_t)n * V + vc) * 3;
+  const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
+  if (live) {
+    if (dverts) {
+      const float *d = dverts + ((size_t)n * V + v) * 3;
+      g0 = d[0]; g1 = d[1]; g2 = d[2];
+    }
+    if (dproj && ((vs <= 1) || (v % vs == 0))) {
+      const float *d = dproj + ((size_t)n * VP + ((vs <= 1) ? v : v / vs)) * 3;
+      const float *c = cam + (size_t)n * x_stride;
+      const float du = d[0], dv = d[1];
+      const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
+      const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
+      g0 += c[0] * du; g1 += c[1] * dv; g2 += d[2];
+      dku = X * du; dkv = Y * dv; du0 = du; dv0 = dv;
+    }
+    float *o = dv_posed + ((size_t)n * V + v) * 3;
+    o[0] = T[0] * g0 + T[4] * g1 + T[8] * g2;
+    o[1] = T[1] * g0 + T[5] * g1 + T[9] * g2;
+    o[2] = T[2] * g0 + T[6] * g1 + T[10] * g2;
+  }
+  sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
+  sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
+  __syncthreads();
+
+  // dA tile on the matrix cores: D[joint][comp] += sum_k w[vk][joint] * g[vk][comp>>2]*ph[vk][comp&3]
+  const int li = lane & 15, lk = lane >> 4;
+  const int cr = li >> 2, cc = li & 3;   // component j = li = r*4+c  (valid for li < 12)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int vbase = blockIdx.x * SKB_T + wave * 64;
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const int k = s * 4 + lk;                 // vertex within the wave's 64
+    int vk = vbase + k;
+    vk = vk < V ? vk : V - 1;                 // tail: g = 0 there, any finite weight is fine
+    const float *wk = lbs + (size_t)vk * 24;
+    const float a0 = wk[li];
+    const float a1 = (li < 8) ? wk[16 + li] : 0.0f;
+    const int t = wave * 64 + k;
+    const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+  }
+  // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
+  if (li < 12) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j0 = lk * 4 + r;
+      sRed[wave][j0 * 12 + li] = acc0[r];
+      if (j0 < 8) sRed[wave][(16 + j0) * 12 + li] = acc1[r];
+    }
+  }
+  const float r0 = wave_sum(dku), r1 = wave_sum(dkv), r2 = wave_sum(du0), r3 = wave_sum(dv0);
+  if (lane == 0) {
+    sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
+  }
+  __syncthreads();
+  if (tid < SKB_PART) {
+    float acc = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][tid];
+    part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + tid] = acc;
+  }
+}
+
+__global__ __launch_bounds__(320) void skin_bwd_reduce_kernel(const float *__restrict__ part, int nblk,
+                                                              float *__restrict__ dA,
+                                                              float *__restrict__ dcam) {
+  const int n = blockIdx.x, e = threadIdx.x;
+  if (e >= SKB_PART) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblk; ++b) acc += part[((size_t)n * nblk + b) * SKB_PART + e];
+  if (e < 288) dA[(size_t)n * 288 + e] = acc;
+  else if (dcam) dcam[(size_t)n * 4 + (e - 288)] = acc;
+}
+
+// ---------------------------------------------------------------- stand-alone projection
+__global__ __launch_bounds__(256) void project_fwd_kernel(const float *__restrict__ verts,
+                                                          const float *__restrict__ cam, int x_stride,
+                                                          int V, int vs, int VP, float *__restrict__ proj) {
+  const int n = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= VP) return;
+  const float *c = cam + (size_t)n * x_stride;
+  const float *p = verts + ((size_t)n * V + (size_t)i * vs) * 3;
+  float *o = proj + ((size_t)n * VP + i) * 3;
+  o[0] = c[2] + p[0] * c[0];
+  o[1] = c[3] + p[1] * c[1];
+  o[2] = p[2];
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restrict__ dproj,
+                                                          const float *__restrict__ verts,
+                                                          const float *__restrict__ cam, int x_stride,
+                                                          int V, int vs, int VP, float *__restrict__ dverts,
+                                                          float *__restrict__ dcam) {
+  __shared__ float red[4][4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float *c = cam + (size_t)n * x_stride;
+  const float ku = c[0], kv = c[1];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    float *o = dverts + ((size_t)n * V + v) * 3;
+    if (vs <= 1 || v % vs == 0) {
+      const float *d = dproj + ((size_t)n * VP + (vs <= 1 ? v : v / vs)) * 3;
+      const float *p = verts + ((size_t)n * V + v) * 3;
+      const float du = d[0], dv = d[1];
+      o[0] = ku * du; o[1] = kv * dv; o[2] = d[2];
+      s0 += p[0] * du; s1 += p[1] * dv; s2 += du; s3 += dv;
+    } else {
+      o[0] = 0.f; o[1] = 0.f; o[2] = 0.f;
+    }
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+  if ((tid & 63) == 0) {
+    red[tid >> 6][0] = s0; red[tid >> 6][1] = s1; red[tid >> 6][2] = s2; red[tid >> 6][3] = s3;
+  }
+  __syncthreads();
+  if (tid < 4) dcam[(size_t)n * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+}  // namespace smplr
+
+extern "C" {
+
+static int check_vs(int V, int vs) { return vs >= 1 && vs <= V; }
+
+int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *A, const float *cam,
+                   int x_stride, int B, int V, int vertex_sampling, float *verts, float *proj,
+                   void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && V > 0 && check_vs(V, vertex_sampling), "smplr_skin_fwd: bad sizes B=%d V=%d vs=%d",
+                B, V, vertex_sampling);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(v_posed && lbs_weights && A && (verts || proj), "smplr_skin_fwd: null pointer");
+  SMPLR_REQUIRE(!proj || (cam && x_stride >= 4), "smplr_skin_fwd: proj requested without camera rows");
+  const int VP = (V + vertex_sampling - 1) / vertex_sampling;
+  dim3 grid((V + 255) / 256, (B + SK_MB - 1) / SK_MB);
+  hipLaunchKernelGGL(skin_fwd_kernel, grid, dim3(256), 0, as_stream(stream), v_posed, lbs_weights, A, cam,
+                     x_stride, B, V, vertex_sampling, VP, verts, proj);
+  SMPLR_LAUNCH_CHECK("smplr_skin_fwd");
+  return 0;
+}
+
+size_t smplr_skin_bwd_workspace(int B, int V) {
+  using namespace smplr;
+  if (B <= 0 || V <= 0) return 0;
+  return (size_t)B * ((V + SKB_T - 1) / SKB_T) * SKB_PART * sizeof(float);
+}
+
+int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed,
+                   const float *lbs_weights, const float *A, const float *cam, int x_stride, int B, int V,
+                   int vertex_sampling, float *dv_posed, float *dA, float *dcam, void *workspace,
+                   void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && V > 0 && check_vs(V, vertex_sampling), "smplr_skin_bwd: bad sizes B=%d V=%d vs=%d",
+                B, V, vertex_sampling);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(v_posed && lbs_weights && A && dv_posed && dA && workspace, "smplr_skin_bwd: null pointer");
+  SMPLR_REQUIRE(dverts || dproj, "smplr_skin_bwd: need dverts and/or dproj");
+  SMPLR_REQUIRE(!dproj || (cam && x_stride >= 4), "smplr_skin_bwd: dproj given without camera rows");
+  const int VP = (V + vertex_sampling - 1) / vertex_sampling;
+  const int nblk = (V + SKB_T - 1) / SKB_T;
+  hipLaunchKernelGGL(skin_bwd_kernel, dim3(nblk, B), dim3(SKB_T), 0, as_stream(stream), dverts, dproj,
+                     v_posed, lbs_weights, A, cam, x_stride, B, V, vertex_sampling, VP, dv_posed,
+                     reinterpret_cast<float *>(workspace));
+  SMPLR_LAUNCH_CHECK("smplr_skin_bwd");
+  hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(B), dim3(320), 0, as_stream(stream),
+                     reinterpret_cast<const float *>(workspace), nblk, dA, dcam);
+  SMPLR_LAUNCH_CHECK("smplr_skin_bwd(reduce)");
+  return 0;
+}
+
+int smplr_project_fwd(const float *verts, const float *cam, int x_stride, int B, int V,
+                      int vertex_sampling, float *proj, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && V > 0 && check_vs(V, vertex_sampling) && x_stride >= 4,
+                "smplr_project_fwd: bad sizes B=%d V=%d vs=%d x_stride=%d", B, V, vertex_sampling, x_stride);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(verts && cam && proj, "smplr_project_fwd: null pointer");
+  const int VP = (V + vertex_sampling - 1) / vertex_sampling;
+  hipLaunchKernelGGL(project_fwd_kernel, dim3((VP + 255) / 256, B), dim3(256), 0, as_stream(stream), verts,
+                     cam, x_stride, V, vertex_sampling, VP, proj);
+  SMPLR_LAUNCH_CHECK("smplr_project_fwd");
+  return 0;
+}
+
+int smplr_project_bwd(const float *dproj, const float *verts, const float *cam, int x_stride, int B, int V,
+                      int vertex_sampling, float *dverts, float *dcam, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && V > 0 && check_vs(V, vertex_sampling) && x_stride >= 4,
+                "smplr_project_bwd: bad sizes B=%d V=%d vs=%d x_stride=%d", B, V, vertex_sampling, x_stride);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(dproj && verts && cam && dverts && dcam, "smplr_project_bwd: null pointer");
+  const int VP = (V + vertex_sampling - 1) / vertex_sampling;
+  hipLaunchKernelGGL(project_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dproj, verts, cam,
+                     x_stride, V, vertex_sampling, VP, dverts, dcam);
+  SMPLR_LAUNCH_CHECK("smplr_project_bwd");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,371 @@
+"""autograd.Functions over the C ABI (include/smplraster.h): the host side of the hot path.
+
+Each Function allocates its outputs / saved tensors with torch (device memory + stream
+plumbing only) and calls the HIP kernels through ctypes on torch's current stream.  There is
+no eager/CPU fallback anywhere in this file.
+
+Reference callables replaced (reference file:line):
+  BatchSMPLFn  - SMPLLayer.call            keras_smpl/batch_smpl.py:96-153
+  ProjectFn    - orthographic_project      keras_smpl/projection.py:54-81
+  visibility   - compute_mask              keras_smpl/compute_mask.py:12-108
+  SegRasterFn  - projects_to_seg           keras_smpl/projects_to_seg.py:9-69
+  SilhRasterFn - projects_to_silhouette    keras_smpl/projects_to_silhouette.py:14-44
+  DecoderFn    - the model.py:108-118 chain of the above as one autograd node
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KPAD, CHUNK, check, ptr, require_cuda, stream
+from .smpl_model import SMPLModelData, load_part_tables
+
+
+# --------------------------------------------------------------------------- constants
+@dataclass
+class SMPLConstants:
+    """Device-resident constants of SMPLLayer.build (keras_smpl/batch_smpl.py:31-93)."""
+    V: int
+    v_template: torch.Tensor    # (3V,)
+    blend: torch.Tensor         # (220, 3V): rows 0..9 shapedirs, 10..216 posedirs, 217..219 zero
+    J_template: torch.Tensor    # (24,3)   = J_regressor @ v_template
+    J_dirs: torch.Tensor        # (24,3,10) = J_regressor @ shapedirs
+    lbs_weights: torch.Tensor   # (V,24)
+    parents: torch.Tensor       # (24,) int32
+    joint_regressor: Optional[torch.Tensor] = None   # (V,19|14) cocoplus / lsp, optional
+
+    @staticmethod
+    def from_model(model: SMPLModelData, device, joint_type: str = "lsp") -> "SMPLConstants":
+        model.validate()
+        V = model.num_verts
+        sd = np.asarray(model.shapedirs, np.float64).reshape(-1, 10).T      # (10,3V)  :50-55
+        pd = np.asarray(model.posedirs, np.float64).reshape(-1, 207).T      # (207,3V) :64-68
+        blend = np.zeros((KPAD, 3 * V), np.float64)
+        blend[:10] = sd
+        blend[10:217] = pd
+        Jreg = np.asarray(model.J_regressor, np.float64)                    # (24,V)
+        J_template = Jreg @ np.asarray(model.v_template, np.float64)        # (24,3)
+        J_dirs = np.einsum("jv,vck->jck", Jreg, np.asarray(model.shapedirs, np.float64))
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(device)
+        jr = None
+        if model.cocoplus_regressor is not None:
+            jr = np.asarray(model.cocoplus_regressor, np.float64).T         # (V,19) :82-85
+            if joint_type == "lsp":
+                jr = jr[:, :14]                                             # :86-87
+            jr = f32(jr)
+        return SMPLConstants(
+            V=V, v_template=f32(np.asarray(model.v_template).reshape(-1)), blend=f32(blend),
+            J_template=f32(J_template), J_dirs=f32(J_dirs), lbs_weights=f32(model.weights),
+            parents=torch.as_tensor(np.asarray(model.parents, np.int32)).to(device),
+            joint_regressor=jr)
+
+
+@dataclass
+class PartTable:
+    """Padded part-major vertex positions for the rasteriser (projects_to_seg.py:18-24,36-37)."""
+    P: int
+    KP: int
+    part_pos: torch.Tensor   # (KP,) int32, -1 padded
+    part_off: torch.Tensor   # (P+1,) int32, multiples of CHUNK
+    VP: int
+
+
+_part_tables = {}
+
+
+def build_part_table(ids, off, vertex_sampling, num_verts, device) -> PartTable:
+    vs = 1 if vertex_sampling in (None, 1) else int(vertex_sampling)
+    P = len(off) - 1
+    pos_list, poff = [], [0]
+    for p in range(P):
+        pos = (np.asarray(ids[off[p]:off[p + 1]], np.int64) // vs).astype(np.int32)
+        pad = (-len(pos)) % CHUNK
+        pos_list.append(np.concatenate([pos, np.full(pad, -1, np.int32)]))
+        poff.append(poff[-1] + len(pos) + pad)
+    part_pos = np.concatenate(pos_list).astype(np.int32)
+    VP = (num_verts + vs - 1) // vs
+    assert part_pos.max() < VP
+    return PartTable(P=P, KP=int(poff[-1]),
+                     part_pos=torch.as_tensor(part_pos).to(device),
+                     part_off=torch.as_tensor(np.asarray(poff, np.int32)).to(device), VP=VP)
+
+
+def get_part_table(vertex_sampling, device, num_verts=6890) -> PartTable:
+    key = (1 if vertex_sampling in (None, 1) else int(vertex_sampling), str(device), num_verts)
+    if key not in _part_tables:
+        ids, off = load_part_tables(vertex_sampling)
+        _part_tables[key] = build_part_table(ids, off, vertex_sampling, num_verts, device)
+    return _part_tables[key]
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _workspace(nbytes, like):
+    return torch.empty(max(int(nbytes), 4) // 4 + 1, dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------- raw stage calls
+def _pose_fwd(x, num_cam, c: SMPLConstants):
+    lib = _lib.load()
+    B = x.shape[0]
+    coef = _empty((B, KPAD), x)
+    Rs = _empty((B, 24, 9), x)
+    J = _empty((B, 24, 3), x)
+    A = _empty((B, 24, 12), x)
+    Jt = _empty((B, 24, 3), x)
+    check(lib.smplr_pose_fwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_template), ptr(c.J_dirs),
+                             ptr(c.parents), ptr(coef), ptr(Rs), ptr(J), ptr(A), ptr(Jt), stream()),
+          "smplr_pose_fwd")
+    return coef, Rs, J, A, Jt
+
+
+def _blend_fwd(coef, c: SMPLConstants):
+    lib = _lib.load()
+    B = coef.shape[0]
+    v_posed = _empty((B, c.V, 3), coef)
+    check(lib.smplr_blend_fwd(ptr(coef), ptr(c.blend), ptr(c.v_template), B, 3 * c.V, ptr(v_posed),
+                              stream()), "smplr_blend_fwd")
+    return v_posed
+
+
+def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_verts=True):
+    lib = _lib.load()
+    B = v_posed.shape[0]
+    vs = int(vertex_sampling)
+    verts = _empty((B, c.V, 3), v_posed) if want_verts else None
+    proj = _empty((B, (c.V + vs - 1) // vs, 3), v_posed) if cam is not None else None
+    check(lib.smplr_skin_fwd(ptr(v_posed), ptr(c.lbs_weights), ptr(A), ptr(cam),
+                             cam.shape[1] if cam is not None else 0, B, c.V, vs, ptr(verts), ptr(proj),
+                             stream()), "smplr_skin_fwd")
+    return verts, proj
+
+
+def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJt, vertex_sampling=1):
+    """dverts and/or dproj (+ optional dJ_transformed) -> dx (B, x_stride)."""
+    lib = _lib.load()
+    B = x.shape[0]
+    vs = int(vertex_sampling)
+    dv_posed = _empty((B, c.V, 3), x)
+    dA = _empty((B, 24, 12), x)
+    dcam = _empty((B, 4), x) if dproj is not None else None
+    ws = _workspace(lib.smplr_skin_bwd_workspace(B, c.V), x)
+    check(lib.smplr_skin_bwd(ptr(dverts), ptr(dproj), ptr(v_posed), ptr(c.lbs_weights), ptr(A),
+                             ptr(x) if dproj is not None else None, x.shape[1], B, c.V, vs,
+                             ptr(dv_posed), ptr(dA), ptr(dcam), ptr(ws), stream()), "smplr_skin_bwd")
+    dcoef = _empty((B, KPAD), x)
+    ws2 = _workspace(lib.smplr_blend_bwd_workspace(B, 3 * c.V), x)
+    check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend), B, 3 * c.V, ptr(dcoef), ptr(ws2), stream()),
+          "smplr_blend_bwd")
+    dx = _empty(tuple(x.shape), x)
+    if x.shape[1] > num_cam + 82:
+        dx.zero_()
+    check(lib.smplr_pose_bwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_dirs), ptr(c.parents), ptr(Rs),
+                             ptr(J), ptr(A), ptr(dcoef), ptr(dA), ptr(dJt), ptr(dx), stream()),
+          "smplr_pose_bwd")
+    if dcam is not None:
+        dx[:, :4] = dcam
+    return dx
+
+
+def visibility(proj, grid_wh=64, ref_compat=True):
+    """compute_mask (keras_smpl/compute_mask.py:12-108), stateless; no gradient (:30)."""
+    lib = _lib.load()
+    proj = require_cuda(proj.detach(), "projects_with_depth")
+    if proj.dim() != 3 or proj.shape[2] != 3:
+        raise RuntimeError("projects_with_depth must be (B, V', 3)")
+    B, VP = proj.shape[0], proj.shape[1]
+    mask = _empty((B, VP), proj)
+    check(lib.smplr_visibility(ptr(proj), B, VP, int(grid_wh), 1 if ref_compat else 0, ptr(mask),
+                               stream()), "smplr_visibility")
+    return mask
+
+
+def _seg_fwd(proj, mask, W, pt: PartTable):
+    lib = _lib.load()
+    B, VP = proj.shape[0], proj.shape[1]
+    if VP != pt.VP:
+        raise RuntimeError("projects has %d vertices but the part table expects %d" % (VP, pt.VP))
+    srt = _empty((B, pt.KP, 4), proj)
+    seg = _empty((B, W, W, pt.P + 1), proj)
+    arg = _empty((B, W, W, 32), proj, torch.int16)
+    check(lib.smplr_seg_fwd(ptr(proj), ptr(mask), B, VP, W, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
+                            pt.KP, ptr(srt), ptr(seg), ptr(arg), stream()), "smplr_seg_fwd")
+    return seg, arg
+
+
+def _seg_bwd(dseg, seg, arg, proj, mask, W, pt: PartTable):
+    lib = _lib.load()
+    B, VP = proj.shape[0], proj.shape[1]
+    dproj = _empty((B, VP, 3), proj)
+    check(lib.smplr_seg_bwd(ptr(dseg), ptr(seg), ptr(arg), ptr(proj), ptr(mask), B, VP, W, pt.P,
+                            ptr(dproj), stream()), "smplr_seg_bwd")
+    return dproj
+
+
+def _silh_fwd(proj, W):
+    lib = _lib.load()
+    B, VP = proj.shape[0], proj.shape[1]
+    silh = _empty((B, W, W, 2), proj)
+    arg = _empty((B, W, W), proj, torch.int32)
+    ws = _workspace(lib.smplr_silh_workspace(B, VP), proj)
+    check(lib.smplr_silh_fwd(ptr(proj), B, VP, W, ptr(silh), ptr(arg), ptr(ws), stream()), "smplr_silh_fwd")
+    return silh, arg
+
+
+def _silh_bwd(dsilh, silh, arg, proj, W):
+    lib = _lib.load()
+    B, VP = proj.shape[0], proj.shape[1]
+    dproj = _empty((B, VP, 3), proj)
+    check(lib.smplr_silh_bwd(ptr(dsilh), ptr(silh), ptr(arg), ptr(proj), B, VP, W, ptr(dproj), stream()),
+          "smplr_silh_bwd")
+    return dproj
+
+
+# --------------------------------------------------------------------------- autograd nodes
+class BatchSMPLFn(torch.autograd.Function):
+    """x (B, num_cam+82) -> verts (B,V,3), J_transformed (B,24,3)."""
+
+    @staticmethod
+    def forward(ctx, x, consts: SMPLConstants, num_cam: int):
+        x = require_cuda(x, "x")
+        coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
+        v_posed = _blend_fwd(coef, consts)
+        verts, _ = _skin_fwd(v_posed, A, consts)
+        ctx.consts, ctx.num_cam = consts, num_cam
+        ctx.save_for_backward(x, Rs, J, A, v_posed)
+        return verts, Jt
+
+    @staticmethod
+    def backward(ctx, dverts, dJt):
+        x, Rs, J, A, v_posed = ctx.saved_tensors
+        dverts = require_cuda(dverts, "dverts") if dverts is not None else None
+        dJt = require_cuda(dJt, "dJ_transformed") if dJt is not None else None
+        if dverts is None:
+            dverts = torch.zeros_like(v_posed)
+        dx = _smpl_bwd(x, ctx.num_cam, ctx.consts, Rs, J, A, v_posed, dverts, None, dJt)
+        return dx, None, None
+
+
+class ProjectFn(torch.autograd.Function):
+    """(verts (B,V,3), smpl (B,>=4)) -> (B,V',3)   (keras_smpl/projection.py:54-81)."""
+
+    @staticmethod
+    def forward(ctx, verts, smpl, vertex_sampling: int):
+        lib = _lib.load()
+        verts = require_cuda(verts, "verts")
+        smpl = require_cuda(smpl, "smpl")
+        B, V = verts.shape[0], verts.shape[1]
+        vs = int(vertex_sampling)
+        proj = _empty((B, (V + vs - 1) // vs, 3), verts)
+        check(lib.smplr_project_fwd(ptr(verts), ptr(smpl), smpl.shape[1], B, V, vs, ptr(proj), stream()),
+              "smplr_project_fwd")
+        ctx.vs = vs
+        ctx.save_for_backward(verts, smpl)
+        return proj
+
+    @staticmethod
+    def backward(ctx, dproj):
+        lib = _lib.load()
+        verts, smpl = ctx.saved_tensors
+        dproj = require_cuda(dproj, "dproj")
+        B, V = verts.shape[0], verts.shape[1]
+        dverts = _empty(tuple(verts.shape), verts)
+        dcam = _empty((B, 4), verts)
+        check(lib.smplr_project_bwd(ptr(dproj), ptr(verts), ptr(smpl), smpl.shape[1], B, V, ctx.vs,
+                                    ptr(dverts), ptr(dcam), stream()), "smplr_project_bwd")
+        dsmpl = torch.zeros_like(smpl)
+        dsmpl[:, :4] = dcam
+        return dverts, dsmpl, None
+
+
+class SegRasterFn(torch.autograd.Function):
+    """(proj (B,V',3), mask (B,V')) -> seg (B,W,W,32)   (keras_smpl/projects_to_seg.py:9-69)."""
+
+    @staticmethod
+    def forward(ctx, proj, mask, img_wh: int, pt: PartTable):
+        proj = require_cuda(proj, "projects_with_depth")
+        mask = require_cuda(mask, "mask_vals")
+        seg, arg = _seg_fwd(proj, mask, int(img_wh), pt)
+        ctx.W, ctx.pt = int(img_wh), pt
+        ctx.save_for_backward(proj, mask, seg, arg)
+        ctx.mark_non_differentiable(arg)
+        return seg, arg
+
+    @staticmethod
+    def backward(ctx, dseg, _darg):
+        proj, mask, seg, arg = ctx.saved_tensors
+        dseg = require_cuda(dseg, "dseg")
+        return _seg_bwd(dseg, seg, arg, proj, mask, ctx.W, ctx.pt), None, None, None
+
+
+class SilhRasterFn(torch.autograd.Function):
+    """proj (B,V',3) -> silh (B,W,W,2)   (keras_smpl/projects_to_silhouette.py:14-44)."""
+
+    @staticmethod
+    def forward(ctx, proj, img_wh: int):
+        proj = require_cuda(proj, "projects_with_depth")
+        silh, arg = _silh_fwd(proj, int(img_wh))
+        ctx.W = int(img_wh)
+        ctx.save_for_backward(proj, silh, arg)
+        ctx.mark_non_differentiable(arg)
+        return silh, arg
+
+    @staticmethod
+    def backward(ctx, dsilh, _darg):
+        proj, silh, arg = ctx.saved_tensors
+        dsilh = require_cuda(dsilh, "dsilh")
+        return _silh_bwd(dsilh, silh, arg, proj, ctx.W), None
+
+
+class DecoderFn(torch.autograd.Function):
+    """The model.py:108-118 chain as ONE autograd node.
+
+    x (B, 86) -> verts (B,V,3), proj (B,V',3), mask (B,V'), seg (B,W,W,32) [, silh (B,W,W,2)].
+    The projection is the skinning kernel's epilogue, the mask is computed in between, and the
+    backward fuses d(seg)/d(silh)/d(verts)/d(proj) into one skinning-backward launch.
+    """
+
+    @staticmethod
+    def forward(ctx, x, consts: SMPLConstants, num_cam, img_wh, vertex_sampling, pt: PartTable,
+                grid_wh, ref_compat, with_silh):
+        x = require_cuda(x, "x")
+        vs = int(vertex_sampling)
+        W = int(img_wh)
+        coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
+        v_posed = _blend_fwd(coef, consts)
+        verts, proj = _skin_fwd(v_posed, A, consts, cam=x, vertex_sampling=vs)
+        mask = visibility(proj, grid_wh, ref_compat)
+        seg, arg = _seg_fwd(proj, mask, W, pt)
+        if with_silh:
+            silh, sarg = _silh_fwd(proj, W)
+        else:
+            silh = sarg = torch.empty(0, device=x.device)
+        ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, with_silh
+        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, mask, seg, arg, silh, sarg)
+        ctx.mark_non_differentiable(mask)
+        return verts, proj, mask, seg, silh, Jt
+
+    @staticmethod
+    def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
+        x, Rs, J, A, v_posed, proj, mask, seg, arg, silh, sarg = ctx.saved_tensors
+        dproj = None
+        if dseg is not None:
+            dproj = _seg_bwd(require_cuda(dseg, "dseg"), seg, arg, proj, mask, ctx.W, ctx.pt)
+        if ctx.with_silh and dsilh is not None:
+            d2 = _silh_bwd(require_cuda(dsilh, "dsilh"), silh, sarg, proj, ctx.W)
+            dproj = d2 if dproj is None else dproj + d2
+        if dproj_in is not None:
+            dproj_in = require_cuda(dproj_in, "dproj")
+            dproj = dproj_in if dproj is None else dproj + dproj_in
+        dverts = require_cuda(dverts, "dverts") if dverts is not None else None
+        dJt = require_cuda(dJt, "dJ_transformed") if dJt is not None else None
+        if dverts is None and dproj is None:
+            dverts = torch.zeros_like(v_posed)
+        dx = _smpl_bwd(x, ctx.num_cam, ctx.consts, Rs, J, A, v_posed, dverts, dproj, dJt, ctx.vs)
+        return (dx,) + (None,) * 8
