@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""bench.py - meshes/s of the hot path: SMPL(86) -> verts(6890x3) -> 48x48 31-part seg, fwd+bwd.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched with
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  A "step" is one forward + backward of the full decoder (BASELINE.json configs[2]: batch_smpl +
+projection + compute_mask + projects_to_seg, B=128 meshes per GPU, W=48) on seeded synthetic
+parameters that are already resident in HBM.  The path shards by mesh with no data-path collective
+(SURVEY.md §8(e)): every rank processes its own B meshes ("weak" scaling), the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is taken.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      - the dominant kernel (segmentation raster forward), timed live with HIP events on
+                  the launch stream; achieved = algorithmic FLOPs per launch / mean launch time
+  cpu_baseline  - the oracle's fp32 reference-shaped torch-CPU restatement timed on this box's host
+                  cores on a bounded sample (rank 0, N=1 only); a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import ilps_amd  # noqa: E402,F401
+from ilps_amd import ops  # noqa: E402
+from ilps_amd.smpl_model import synthetic_smpl_model, mean86, load_part_tables  # noqa: E402
+
+# algorithmic work of the segmentation raster forward per mesh at W=48:
+# 2304 px x 6879 part vertices = 15.85 M pair-evals x 7 FLOP + 71,424 (pixel,part) x (sqrt, exp).
+SEG_FWD_FLOP_PER_MESH = 2304 * 6879 * 7 + 2304 * 31 * 2
+FP32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak == fp32 MFMA peak
+HBM_PEAK_GBS = 8000.0
+
+
+def make_x(B, W, seed):
+    rng = np.random.default_rng(seed)
+    x = np.tile(mean86(W), (B, 1))
+    x[:, 0:2] += rng.normal(0.0, 1.0, (B, 2))
+    x[:, 2:4] += rng.normal(0.0, 0.05 * W, (B, 2))
+    x[:, 4:76] += rng.normal(0.0, 0.2, (B, 72))
+    x[:, 76:86] += rng.normal(0.0, 1.0, (B, 10))
+    return x.astype(np.float32)
+
+
+def event_time_ms(fn, reps, stream):
+    """Mean duration of fn() in ms, HIP events recorded on the stream fn launches on."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    fn()
+    stream.synchronize()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def stage_breakdown(x, consts, pt, W, reps=20):
+    """Per-C-ABI-call mean times (us) on the current stream; same kernels as the timed step."""
+    st = torch.cuda.current_stream()
+    B = x.shape[0]
+    res = {}
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts)
+    res["pose_fwd"] = event_time_ms(lambda: ops._pose_fwd(x, 4, consts), reps, st)
+    v_posed = ops._blend_fwd(coef, consts)
+    res["blend_fwd"] = event_time_ms(lambda: ops._blend_fwd(coef, consts), reps, st)
+    verts, proj = ops._skin_fwd(v_posed, A, consts, cam=x)
+    res["skin_fwd"] = event_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
+    mask = ops.visibility(proj)
+    res["visibility"] = event_time_ms(lambda: ops.visibility(proj), reps, st)
+    seg, arg = ops._seg_fwd(proj, mask, W, pt)
+    res["seg_fwd"] = event_time_ms(lambda: ops._seg_fwd(proj, mask, W, pt), reps, st)
+    dseg = torch.randn_like(seg)
+    dproj = ops._seg_bwd(dseg, seg, arg, proj, mask, W, pt)
+    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, seg, arg, proj, mask, W, pt), reps, st)
+    res["smpl_bwd(skin+blend+pose)"] = event_time_ms(
+        lambda: ops._smpl_bwd(x, 4, consts, Rs, J, A, v_posed, None, dproj, None), reps, st)
+    return {k: round(v * 1e3, 2) for k, v in res.items()}
+
+
+def cpu_baseline(model, W, budget_s=20.0):
+    """fp32 reference-shaped CPU restatement (oracle/torch_oracle.py), fwd+bwd, bounded sample."""
+    from oracle import torch_oracle as to
+    from oracle import np_oracle as no
+    # the GPU box's CPU share for one GPU is 16 cores whatever os.cpu_count() says
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(avail, 16))
+    torch.set_num_threads(ncores)
+    ids, off = load_part_tables(1)
+    smpl = to.TorchSMPL(model, dtype=torch.float32)
+    Bc = 1
+    x = torch.tensor(make_x(Bc, W, 123), requires_grad=True)
+    g = torch.randn(Bc, W, W, 32)
+
+    def one():
+        if x.grad is not None:
+            x.grad = None
+        verts, proj, mask, seg = to.decoder_forward(
+            smpl, x, lambda p: torch.tensor(no.compute_mask(p.numpy().astype(np.float64)), dtype=torch.float32),
+            W, ids, off)
+        (seg * g).sum().backward()
+
+    one()                                   # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {"value": round(Bc * n / el, 3), "unit": "meshes/s", "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": "%d fwd+bwd passes of the full decoder at B=%d, W=%d (%.1f s); fp32 torch-CPU "
+                      "restatement of the reference's dense formulation (TensorFlow itself is not "
+                      "installable here)" % (n, Bc, W, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128, help="meshes per GPU")
+    ap.add_argument("--wh", type=int, default=48)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, W = args.batch, args.wh
+    model = synthetic_smpl_model(1234)
+    consts = ops.SMPLConstants.from_model(model, dev)
+    pt = ops.get_part_table(1, dev, consts.V)
+    x = torch.tensor(make_x(B, W, 1000 + rank), device=dev)      # resident in HBM before timing
+    gen = torch.Generator(device="cpu").manual_seed(rank)
+    dseg = torch.randn(B, W, W, 32, generator=gen).to(dev)
+
+    def step():
+        xg = x.detach().requires_grad_(True)
+        verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False)
+        seg.backward(dseg)
+        return xg.grad
+
+    mode = args.mode
+    run = step
+    graph = None
+    if mode == "graph":
+        try:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_grad = step()
+            run = graph.replay
+        except Exception as e:  # capture unsupported -> eager, reported in config
+            sys.stderr.write("bench: HIP graph capture failed (%s); running eager\n" % e)
+            mode = "eager"
+            graph = None
+            run = step
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    line = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "meshes/sec fwd+bwd (SMPL->48x48 31-part seg)",
+            "value": round(value, 1), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
+                                   "projects_to_seg), BASELINE configs[2]",
+                       "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,
+                       "params_per_mesh": 86, "launch": mode, "sharding": "by mesh, no collective"},
+        }
+        if not args.no_breakdown:
+            stages = stage_breakdown(x, consts, pt, W)
+            line["stages_us"] = stages
+            t_seg = stages["seg_fwd"] * 1e-6
+            flop = SEG_FWD_FLOP_PER_MESH * B if W == 48 else (W * W * 6879 * 7 + W * W * 62) * B
+            ach = flop / t_seg / 1e12
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get("seg_fwd_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            line["roofline"] = {
+                "kernel": "raster_fwd_kernel<false> (smplr_seg_fwd)", "bound": "mfma",
+                "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                "note": "compute roof: the pair loop runs on the fp32 VALU, whose peak equals the "
+                        "fp32 MFMA peak (157.3 TF); algorithmic FLOPs = SURVEY §8(d) 111 MFLOP/mesh x B",
+                "launch_us": stages["seg_fwd"],
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(model, W)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

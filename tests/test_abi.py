@@ -1,0 +1,56 @@
+"""The C ABI: every function declared in include/smplraster.h is exported by the shared library
+and bound by the ctypes table (no compute calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "smplraster.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smplr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("smplr_pose_fwd", "smplr_pose_bwd", "smplr_blend_fwd", "smplr_blend_bwd", "smplr_skin_fwd",
+                 "smplr_skin_bwd", "smplr_project_fwd", "smplr_project_bwd", "smplr_visibility",
+                 "smplr_seg_fwd", "smplr_seg_bwd", "smplr_silh_fwd", "smplr_silh_bwd"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from ilps_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail("libsmplraster_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(lib, name), "symbol %s missing from the shared library" % name
+
+
+def test_ctypes_table_matches_header():
+    from ilps_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    lib = _lib.load()
+    assert lib.smplr_abi_version() == 1
+    # argument errors are reported without touching the GPU
+    rc = lib.smplr_visibility(None, 1, 6890, 0, 1, None, None)
+    assert rc == -1 and b"grid_wh" in lib.smplr_last_error()
+    assert lib.smplr_blend_bwd_workspace(128, 20670) > 0
+    assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 14 * 292 * 4
+
+
+def test_argument_counts_match_header():
+    from ilps_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_res, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\(([^)]*)\)" % name, src)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), "%s: header has %d parameters, ctypes table %d" % (name, n, len(args))

@@ -1,0 +1,73 @@
+"""Golden vectors (tests/golden/, made by tools/make_golden.py with the float64 oracle).
+
+CPU: the oracle still reproduces them (regression pin).  GPU: the HIP path matches them.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "decoder_*.npz")))
+
+
+def _cfg(path):
+    name = os.path.basename(path)[:-4].split("_")
+    W, vs = int(name[1][1:]), int(name[2][2:])
+    return W, (None if vs == 1 else vs)
+
+
+def test_fixtures_present():
+    assert len(GOLD) == 3
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_oracle_reproduces_golden(path, smpl_model, part_tables):
+    from oracle import np_oracle as o
+    W, vs = _cfg(path)
+    z = np.load(path)
+    x = z["x"].astype(np.float64)
+    r = o.smpl_layer_call(x, smpl_model, return_all=True)
+    assert np.abs(r["verts"] - z["verts"]).max() < 1e-6           # stored as float32
+    proj = o.orthographic_project(r["verts"], x, vs)
+    mask = o.compute_mask(proj)
+    assert np.array_equal(np.packbits(mask == 1.0, axis=1), z["mask_visible"])
+    ids, off = part_tables[vs or 1]
+    seg = o.projects_to_seg(proj[:1], mask[:1], W, ids, off, vs)
+    assert np.abs(seg - z["seg"][:1]).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_hip_matches_golden(path, smpl_model):
+    from ilps_amd.decoder import SMPLDecoder
+    W, vs = _cfg(path)
+    z = np.load(path)
+    dev = torch.device("cuda:0")
+    with_silh = "silh" in z.files
+    dec = SMPLDecoder(smpl_model, img_wh=W, vertex_sampling=vs, with_silhouette=with_silh)
+    x = torch.tensor(z["x"], device=dev, requires_grad=True)
+    out = dec(x)
+    assert np.abs(out["verts"].detach().cpu().numpy() - z["verts"]).max() <= 1e-4
+    assert np.abs(out["J_transformed"].detach().cpu().numpy() - z["J_transformed"]).max() <= 1e-4
+    vis = (out["mask"].cpu().numpy() == 1.0)
+    want_vis = np.unpackbits(z["mask_visible"], axis=1)[:, :vis.shape[1]].astype(bool)
+    # fp32 vertices differ from the float64 oracle's by ~1e-6 px: a handful of vertices may round
+    # to the other pixel; everything else must agree exactly
+    assert (vis != want_vis).mean() < 2e-3
+    seg, want = out["seg"].detach().cpu().numpy(), z["seg"]
+    close = np.abs(seg - want) <= 1e-3 * np.abs(want) + 1e-4
+    assert close.mean() > 0.999
+    rng = np.random.default_rng(W)
+    gs = torch.tensor(rng.normal(0, 1, want.shape).astype(np.float32), device=dev)
+    loss = (out["seg"] * gs).sum()
+    if with_silh:
+        s = out["silhouette"].detach().cpu().numpy()
+        assert np.all(np.abs(s - z["silh"]) <= 1e-3 * np.abs(z["silh"]) + 1e-5)
+        loss = loss + (out["silhouette"] * torch.tensor(z["cot_silh"], device=dev)).sum()
+    loss.backward()
+    got, dx = x.grad.cpu().numpy(), z["dx"]
+    if (vis != want_vis).sum() == 0:          # identical visibility -> gradients comparable
+        for sl in (slice(0, 4), slice(4, 76), slice(76, 86)):
+            assert np.abs(got[:, sl] - dx[:, sl]).max() <= 5e-3 * np.abs(dx[:, sl]).max()

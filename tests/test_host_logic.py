@@ -1,0 +1,114 @@
+"""Host-side logic that needs no GPU: fixtures, synthetic model, part tables, conditioning ops,
+loud failure of the HIP ops on CPU tensors."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_part_tables(part_tables):
+    for vs, n in ((1, 6879), (2, 3438), (5, 1376)):
+        ids, off = part_tables[vs]
+        assert len(ids) == n and len(off) == 32 and off[0] == 0 and off[-1] == n
+        assert len(np.unique(ids)) == n and np.all(ids % vs == 0) and ids.max() < 6890
+        sizes = np.diff(off)
+        assert sizes.min() > 0
+    assert np.diff(part_tables[1][1]).min() == 45 and np.diff(part_tables[1][1]).max() == 710
+
+
+def test_padded_part_table():
+    from ilps_amd import ops
+    from ilps_amd.smpl_model import load_part_tables
+    for vs in (1, 2, 5):
+        ids, off = load_part_tables(vs)
+        pt = ops.build_part_table(ids, off, vs, 6890, "cpu")
+        po, pp = pt.part_off.numpy(), pt.part_pos.numpy()
+        assert pt.P == 31 and np.all(po % 8 == 0) and po[-1] == pt.KP == len(pp)
+        assert pt.VP == (6890 + vs - 1) // vs
+        for p in range(31):
+            seg = pp[po[p]:po[p + 1]]
+            real = seg[seg >= 0]
+            assert np.array_equal(real, ids[off[p]:off[p + 1]] // vs)
+            assert np.all(seg[len(real):] == -1) and len(seg) - len(real) < 8
+
+
+def test_synthetic_model(smpl_model):
+    m = smpl_model
+    m.validate()
+    assert np.allclose(m.weights.sum(1), 1) and (m.weights >= 0).all() and ((m.weights > 0).sum(1) <= 4).all()
+    assert np.allclose(m.J_regressor.sum(1), 1) and (m.J_regressor >= 0).all()
+    h = m.v_template[:, 1].max() - m.v_template[:, 1].min()
+    assert 1.5 < h < 2.0
+    from ilps_amd.smpl_model import synthetic_smpl_model
+    m2 = synthetic_smpl_model(1234)
+    assert np.array_equal(m.v_template, m2.v_template) and np.array_equal(m.posedirs, m2.posedirs)
+
+
+def test_mean_params_and_conditioning_ops():
+    from ilps_amd.smpl_model import load_mean_params, mean86
+    from ilps_amd.keras_smpl.set_cam_params import set_cam_params, load_mean_set_cam_params
+    from ilps_amd.keras_smpl.concat_mean_param import concat_mean_param
+    from oracle import np_oracle as o
+    pose, shape = load_mean_params()
+    assert pose.shape == (72,) and shape.shape == (10,) and np.all(pose[:3] == 0)
+    assert abs(shape[0] - 0.20560974) < 1e-7 and abs(pose[3] + 0.22387259) < 1e-7
+    assert mean86(48)[:4].tolist() == [24, 24, 24, 30]
+    rng = np.random.default_rng(0)
+    s = rng.normal(0, 1, (3, 86)).astype(np.float32)
+    for W in (48, 64):
+        assert np.allclose(set_cam_params(torch.tensor(s), W).numpy(), o.set_cam_params(s, W), atol=1e-6)
+        assert np.allclose(load_mean_set_cam_params(torch.tensor(s), W).numpy(),
+                           o.load_mean_set_cam_params(s, W, pose, shape), atol=1e-6)
+    f = rng.normal(0, 1, (3, 2048)).astype(np.float32)
+    got = concat_mean_param(torch.tensor(f), 48).numpy()
+    assert got.shape == (3, 2134)
+    assert np.allclose(got, o.concat_mean_param(f, 48, pose, shape), atol=1e-6)
+
+
+def test_smpl_constants_layout(smpl_model):
+    from ilps_amd import ops
+    c = ops.SMPLConstants.from_model(smpl_model, "cpu")
+    assert c.blend.shape == (220, 20670) and torch.all(c.blend[217:] == 0)
+    S = smpl_model.shapedirs.reshape(-1, 10).T
+    P = smpl_model.posedirs.reshape(-1, 207).T
+    assert np.allclose(c.blend[:10].numpy(), S, atol=1e-7) and np.allclose(c.blend[10:217].numpy(), P, atol=1e-7)
+    # J = J_template + J_dirs.beta equals regressing the shaped vertices (batch_smpl.py:106-115)
+    beta = np.random.default_rng(1).normal(0, 1, 10)
+    v_shaped = (beta @ S).reshape(-1, 3) + smpl_model.v_template
+    J = smpl_model.J_regressor @ v_shaped
+    J2 = c.J_template.numpy().astype(np.float64) + c.J_dirs.numpy().astype(np.float64) @ beta
+    assert np.abs(J - J2).max() < 1e-6
+
+
+def test_hip_ops_refuse_cpu_tensors(smpl_model):
+    """There is no CPU fallback: CPU tensors must raise, not silently compute."""
+    from ilps_amd.keras_smpl.batch_smpl import SMPLLayer
+    from ilps_amd.keras_smpl.compute_mask import compute_mask
+    from ilps_amd.keras_smpl.projection import orthographic_project
+    from ilps_amd.keras_smpl.projects_to_seg import projects_to_seg
+    from ilps_amd.keras_smpl.projects_to_silhouette import projects_to_silhouette
+    layer = SMPLLayer(smpl_model)
+    assert layer.compute_output_shape((7, 86)) == (7, 6890, 3)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        layer(torch.zeros(1, 86))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        orthographic_project([torch.zeros(1, 6890, 3), torch.zeros(1, 86)], None)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        compute_mask(torch.zeros(1, 6890, 3))
+    with pytest.raises(RuntimeError):
+        projects_to_seg([torch.zeros(1, 6890, 3), torch.ones(1, 6890)], 48)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        projects_to_silhouette(torch.zeros(1, 6890, 3), 48)
+    with pytest.raises(RuntimeError, match="shape"):
+        layer(torch.zeros(1, 85))
+
+
+def test_shard_range():
+    from ilps_amd.sharding import shard_range
+    for B, world in ((1024, 8), (10, 4), (3, 8), (0, 2)):
+        spans = [shard_range(B, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == B
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
