@@ -79,8 +79,8 @@ def stage_breakdown(x, consts, pt, W, reps=20):
     seg, arg = ops._seg_fwd(proj, mask, W, pt)
     res["seg_fwd"] = event_time_ms(lambda: ops._seg_fwd(proj, mask, W, pt), reps, st)
     dseg = torch.randn_like(seg)
-    dproj = ops._seg_bwd(dseg, seg, arg, proj, mask, W, pt)
-    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, seg, arg, proj, mask, W, pt), reps, st)
+    dproj = ops._seg_bwd(dseg, arg, proj, mask, W, pt)
+    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, arg, proj, mask, W, pt), reps, st)
     res["smpl_bwd(skin+blend+pose)"] = event_time_ms(
         lambda: ops._smpl_bwd(x, 4, consts, Rs, J, A, v_posed, None, dproj, None), reps, st)
     return {k: round(v * 1e3, 2) for k, v in res.items()}

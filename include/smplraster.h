@@ -55,13 +55,14 @@ int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B,
                    float *coef, float *Rs, float *J, float *A, float *J_transformed,
                    void *stream);
 
-/* Backward of the above.  dcoef (B,220), dA (B,24,12), dJ_transformed (B,24,3) or NULL.
- * Writes dx (B, x_stride) columns [num_cam, num_cam+82); camera columns are zeroed.        */
+/* Backward of the above.  dcoef (B,220), dA (B,24,12), dJ_transformed (B,24,3) or NULL,
+ * dcam (B,4) or NULL (d[k_u,k_v,u0,v0] from the projection, smplr_skin_bwd).
+ * Writes dx (B, x_stride) columns [0, num_cam+82): camera columns = dcam (first 4) or 0.     */
 int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B,
                    const float *J_dirs, const int32_t *parents,
                    const float *Rs, const float *J, const float *A,
                    const float *dcoef, const float *dA, const float *dJ_transformed,
-                   float *dx, void *stream);
+                   const float *dcam, float *dx, void *stream);
 
 /* Blend shapes (batch_smpl.py:106-108 and :126-128 as ONE fp32-MFMA GEMM):
  *   v_posed (B,N3) = coef (B,220) x blend (220,N3) + v_template (N3),  N3 = 3*V.
@@ -69,9 +70,11 @@ int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B,
 int smplr_blend_fwd(const float *coef, const float *blend, const float *v_template,
                     int B, int N3, float *v_posed, void *stream);
 
-/* dcoef (B,220) = dv_posed (B,N3) x blend^T.  workspace: smplr_blend_bwd_workspace(B) bytes. */
+/* dcoef (B,220) = dv_posed (B,N3) x blend^T.  blend_t (N3,224) is blend transposed with rows
+ * zero-padded to 224 floats (a second constant, so that neither GEMM transposes the big
+ * matrix).  workspace: smplr_blend_bwd_workspace(B,N3) bytes (split-K partials, summed in order). */
 size_t smplr_blend_bwd_workspace(int B, int N3);
-int smplr_blend_bwd(const float *dv_posed, const float *blend, int B, int N3,
+int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3,
                     float *dcoef, void *workspace, void *stream);
 
 /* Linear-blend skinning (batch_smpl.py:135-145) with the orthographic projection
@@ -111,23 +114,27 @@ int smplr_visibility(const float *proj, int B, int VP, int grid_wh, int ref_comp
 
 /* ---- projects_to_seg: keras_smpl/projects_to_seg.py:9-69 -------------------------------- */
 /* Part table, built once on the host from part_vertices.pkl (projects_to_seg.py:18-24,36-37):
- *   part_pos (KP) int32: positions into the VP-long vertex list, part-major, each part padded
- *                        to a multiple of SMPLR_CHUNK with -1;
- *   part_off (P+1) int32: padded offsets (multiples of SMPLR_CHUNK).
- * sorted (B,KP,4) is scratch the call fills: (u, v, mask^2, mask) per slot.
+ *   part_pos (K) int32: positions into the VP-long vertex list, part-major (K = 6879);
+ *   part_off (P+1) int32: CSR offsets of the P parts.
+ * mask values must be >= 0 (the reference produces {1, 500}).
+ * workspace: smplr_seg_workspace(B,VP,W,P,K) bytes of scratch the call fills (per-mesh lists of
+ *   far-reaching vertices, part-major, and of nearest-pixel-only vertices, pixel-major).
  * seg (B,W,W,P+1): channel 0 = 1 - clip(sum_p score_p, 0, 1); channel 1+p =
- *   max_v exp(-mask_v * |proj_v - (c,r)|); rows flipped (:68).
- * arg (B,W,W,32) int16: slots 0..P-1 = position (in the VP list) of the maximising vertex,
- *   slot 31 = 1 iff 0 <= sum_p <= 1 (the clip's pass-through gate).  Requires P <= 31.      */
+ *   max_v exp(-mask_v * |proj_v - (c,r)|); rows flipped (:68).  Scores below the fp32
+ *   underflow threshold (mask*d >= 104) are exactly 0, as they are in fp32 arithmetic.
+ * arg (B,W,W,32) int16, slot = channel: slot 0 = 1 iff 0 <= sum_p <= 1 (the clip's pass-through
+ *   gate), slot 1+p = position (in the VP list) of the maximising vertex of part p, or -1 when
+ *   no vertex contributes a non-zero score.  Requires P <= 31, VP <= 32767, W <= 160.          */
+size_t smplr_seg_workspace(int B, int VP, int W, int P, int K);
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W,
-                  const int32_t *part_pos, const int32_t *part_off, int P, int KP,
-                  float *sorted, float *seg, int16_t *arg, void *stream);
+                  const int32_t *part_pos, const int32_t *part_off, int P, int K,
+                  void *workspace, float *seg, int16_t *arg, void *stream);
 
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
- * the first arg-min vertex only; it is 0 where the distance is 0 (TF: NaN).                 */
-int smplr_seg_bwd(const float *dseg, const float *seg, const int16_t *arg,
-                  const float *proj, const float *mask, int B, int VP, int W, int P,
-                  float *dproj, void *stream);
+ * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:
+ * NaN).  The score is recomputed from the arg-min vertex, so seg itself is not an input.      */
+int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *proj, const float *mask,
+                  int B, int VP, int W, int P, float *dproj, void *stream);
 
 /* ---- projects_to_silhouette: keras_smpl/projects_to_silhouette.py:14-44 ----------------- */
 /* silh (B,W,W,2) = [1-s, s], s = max_v exp(-|proj_v-(c,r)|/1.2) over ALL VP vertices, rows

@@ -26,7 +26,7 @@ SIGNATURES = {
     "smplr_abi_version": (c_int, []),
     "smplr_last_error": (c_char_p, []),
     "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P]),
-    "smplr_pose_bwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "smplr_pose_bwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "smplr_blend_fwd": (c_int, [P, P, P, I, I, P, P]),
     "smplr_blend_bwd_workspace": (c_size_t, [I, I]),
     "smplr_blend_bwd": (c_int, [P, P, I, I, P, P, P]),
@@ -36,8 +36,9 @@ SIGNATURES = {
     "smplr_project_fwd": (c_int, [P, P, I, I, I, I, P, P]),
     "smplr_project_bwd": (c_int, [P, P, P, I, I, I, I, P, P, P]),
     "smplr_visibility": (c_int, [P, I, I, I, I, P, P]),
+    "smplr_seg_workspace": (c_size_t, [I, I, I, I, I]),
     "smplr_seg_fwd": (c_int, [P, P, I, I, I, P, P, I, I, P, P, P, P]),
-    "smplr_seg_bwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P]),
+    "smplr_seg_bwd": (c_int, [P, P, P, P, I, I, I, I, P, P]),
     "smplr_silh_workspace": (c_size_t, [I, I]),
     "smplr_silh_fwd": (c_int, [P, I, I, I, P, P, P, P]),
     "smplr_silh_bwd": (c_int, [P, P, P, P, I, I, I, P, P]),

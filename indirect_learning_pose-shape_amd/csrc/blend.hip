@@ -13,10 +13,10 @@
 // map keeps the mesh tiles that share a column block on one XCD (blocks b and b+8 share an
 // L2), so blend is fetched from HBM/MALL once and re-read from L2.
 //
-// Backward tiling: workgroup = 32 meshes x all 220 outputs (7 tiles) x one K-slice of
-// columns; both operands are transposed through LDS in 64-column chunks; the 4 waves split
-// each chunk's columns, are summed in LDS in a fixed order, and the per-slice partials are
-// summed by a second kernel in slice order (deterministic, no atomics).
+// Backward tiling: workgroup = 32 meshes x all 220 outputs (7 tiles) x one slice of columns,
+// against the TRANSPOSED constant blendT (N3 x 224) so that no operand of the big matrix needs a
+// transpose; the 4 waves split the slice, are summed in LDS in a fixed order, and the per-slice
+// partials are summed by a second kernel in slice order (deterministic, no atomics).
 #include "common.h"
 
 namespace smplr {
@@ -89,25 +89,27 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------- backward (split-K)
-constexpr int BW_KC = 64;            // columns per LDS chunk
-constexpr int BW_LD = BW_KC + 1;     // 65: odd stride -> conflict-free transposed reads
+// dcoef[m][k] = sum_c dvp[m][c] * blendT[c][k].  blendT = blend transposed, rows padded to 224
+// floats, so the B operand (lanes along k) is read straight from global in MFMA layout (two
+// 128-B row segments per load) exactly like the forward; only the small A operand (32 meshes x
+// 32 columns per stage) is transposed, through a wave-private LDS tile.  The 4 waves of a block
+// split the block's column slice, so there is no block barrier in the main loop.
 constexpr int BW_NT = 7;             // 7 x 32 = 224 >= 220 outputs
-constexpr int BW_NO = 224;
+constexpr int BW_NO = 224;           // blendT row stride and partial row stride
+constexpr int BW_ST = 32;            // columns per wave stage
+constexpr int BW_LD = 33;
 
 __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dvp,
-                                                        const float *__restrict__ blend, int B, int N3,
-                                                        int nslices, int nchunks,
-                                                        float *__restrict__ part) {
-  extern __shared__ float smem[];
-  float *sD = smem;                    // [32][65]
-  float *sB = smem + 32 * BW_LD;       // [220][65]   (reused as the [32][224] reduction buffer)
+                                                        const float *__restrict__ blendT, int B, int N3,
+                                                        int cols_per_block, float *__restrict__ part) {
+  __shared__ float smem[32 * BW_NO];          // 28,672 B: 4 wave tiles (4 x 32 x 33) then the reduction buffer
   const int slice = blockIdx.x, mt = blockIdx.y;
   const int m0 = mt * 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
-  // chunk range of this slice (balanced)
-  const int c_beg = (int)((long long)nchunks * slice / nslices);
-  const int c_end = (int)((long long)nchunks * (slice + 1) / nslices);
+  float *sAw = smem + wave * (BW_ST * BW_LD);
+  const int cw = cols_per_block / 4;
+  const int c_beg = slice * cols_per_block + wave * cw, c_end = c_beg + cw;
 
   f32x16 acc[BW_NT];
 #pragma unroll
@@ -115,35 +117,34 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  for (int ch = c_beg; ch < c_end; ++ch) {
-    const int col0 = ch * BW_KC;
-    __syncthreads();
-    for (int e = tid; e < 32 * BW_KC; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      const int m = m0 + r, cc = col0 + c;
-      sD[r * BW_LD + c] = (m < B && cc < N3) ? dvp[(size_t)m * N3 + cc] : 0.0f;
+  for (int c0 = c_beg; c0 < c_end; c0 += BW_ST) {
+    if (c0 >= N3) break;                       // wave-uniform
+    // stage A: 32 meshes x 32 columns, coalesced along c, stored [c][mesh]
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 2 + h, col = i;
+      const int m = m0 + row, cc = c0 + col;
+      sAw[col * BW_LD + row] = (m < B && cc < N3) ? dvp[(size_t)m * N3 + cc] : 0.0f;
     }
-    for (int e = tid; e < KP * BW_KC; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      const int cc = col0 + c;
-      sB[r * BW_LD + c] = (cc < N3) ? blend[(size_t)r * N3 + cc] : 0.0f;
-    }
-    __syncthreads();
-    // wave w owns columns [16w, 16w+16) of the chunk: 8 k-steps of 2
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int kk = wave * 16 + s * 2 + h;
-      const float a = sD[i * BW_LD + kk];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int s = 0; s < BW_ST / 2; ++s) {
+      const int kk = 2 * s + h;
+      const float a = sAw[kk * BW_LD + i];
+      int cr = c0 + kk;
+      cr = cr < N3 ? cr : N3 - 1;              // a == 0 there
+      const float *brow = blendT + (size_t)cr * BW_NO + i;
 #pragma unroll
       for (int t = 0; t < BW_NT; ++t) {
-        const int j = t * 32 + i;
-        const float b = (j < KP) ? sB[j * BW_LD + kk] : 0.0f;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[t * 32], acc[t], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
   }
   // fixed-order reduction of the 4 waves through LDS, then one partial per (slice, mesh tile)
-  float *sR = sB;  // [32][224]
+  float *sR = smem;  // [32][224]
   for (int w = 0; w < 4; ++w) {
     __syncthreads();
     if (wave == w) {
@@ -169,18 +170,22 @@ __global__ __launch_bounds__(256) void blend_bwd_reduce_kernel(const float *__re
   if (e >= B * KP) return;
   const int m = e / KP, k = e % KP;
   const int mt = m >> 5, r = m & 31;
+  const float *p = part + (size_t)mt * (32 * BW_NO) + r * BW_NO + k;
+  const size_t stride = (size_t)nmt * (32 * BW_NO);
   float acc = 0.0f;
-  for (int s = 0; s < nslices; ++s) acc += part[((size_t)s * nmt + mt) * (32 * BW_NO) + r * BW_NO + k];
+#pragma unroll 8
+  for (int s = 0; s < nslices; ++s) acc += p[s * stride];
   dcoef[e] = acc;
 }
 
-static int bwd_slices(int B, int N3) {
+static void bwd_geometry(int B, int N3, int *nslices, int *cols_per_block) {
   const int nmt = (B + 31) / 32;
-  const int nchunks = (N3 + BW_KC - 1) / BW_KC;
-  int s = (256 + nmt - 1) / nmt;  // ~one block per CU
-  if (s < 8) s = 8;
-  if (s > nchunks) s = nchunks;
-  return s;
+  int target = (256 + nmt - 1) / nmt;          // ~one block per CU
+  if (target < 8) target = 8;
+  int cpb = (N3 + target - 1) / target;
+  cpb = (cpb + 127) / 128 * 128;               // 4 waves x stages of 32 columns
+  *cols_per_block = cpb;
+  *nslices = (N3 + cpb - 1) / cpb;
 }
 
 }  // namespace smplr
@@ -204,26 +209,22 @@ int smplr_blend_fwd(const float *coef, const float *blend, const float *v_templa
 size_t smplr_blend_bwd_workspace(int B, int N3) {
   using namespace smplr;
   if (B <= 0 || N3 <= 0) return 0;
-  const int nmt = (B + 31) / 32;
-  return (size_t)bwd_slices(B, N3) * nmt * 32 * BW_NO * sizeof(float);
+  int ns, cpb;
+  bwd_geometry(B, N3, &ns, &cpb);
+  return (size_t)ns * ((B + 31) / 32) * 32 * BW_NO * sizeof(float);
 }
 
-int smplr_blend_bwd(const float *dv_posed, const float *blend, int B, int N3, float *dcoef,
+int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3, float *dcoef,
                     void *workspace, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && N3 > 0, "smplr_blend_bwd: bad sizes B=%d N3=%d", B, N3);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(dv_posed && blend && dcoef && workspace, "smplr_blend_bwd: null pointer");
-  const int nmt = (B + 31) / 32, nchunks = (N3 + BW_KC - 1) / BW_KC, ns = bwd_slices(B, N3);
-  const size_t lds = (size_t)(32 * BW_LD + KP * BW_LD) * sizeof(float);  // 65,520 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blend_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(ns, nmt), dim3(256), lds, as_stream(stream), dv_posed, blend,
-                     B, N3, ns, nchunks, reinterpret_cast<float *>(workspace));
+  SMPLR_REQUIRE(dv_posed && blend_t && dcoef && workspace, "smplr_blend_bwd: null pointer");
+  const int nmt = (B + 31) / 32;
+  int ns, cpb;
+  bwd_geometry(B, N3, &ns, &cpb);
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(ns, nmt), dim3(256), 0, as_stream(stream), dv_posed, blend_t, B, N3,
+                     cpb, reinterpret_cast<float *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_blend_bwd");
   hipLaunchKernelGGL(blend_bwd_reduce_kernel, dim3((B * KP + 255) / 256), dim3(256), 0,
                      as_stream(stream), reinterpret_cast<const float *>(workspace), B, ns, nmt, dcoef);

@@ -20,6 +20,14 @@ void set_error(const char *fmt, ...) {
 
 constexpr int MPB = 4;  // meshes (waves) per block
 
+// Each wave owns its mesh's LDS region, so ordering LDS traffic inside the wave is enough.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct PoseLds {
   float Rs[24][9];
   float J[24][3];
@@ -125,13 +133,13 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
       J_out[(size_t)n * 72 + e] = acc;
     }
   }
-  __syncthreads();
+  wave_sync();
   // root
   if (live && lane < 12) {
     const int r = lane >> 2, c = lane & 3;
     L.G[0][lane] = (c < 3) ? L.Rs[0][r * 3 + c] : L.J[0][r];
   }
-  __syncthreads();
+  wave_sync();
   for (int i = 1; i < 24; ++i) {
     const int p = parents[i];
     if (live && lane < 12) {
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
       }
       L.G[i][lane] = acc;
     }
-    __syncthreads();
+    wave_sync();
   }
   if (live) {
     for (int e = lane; e < 288; e += 64) {
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     const float *__restrict__ J_dirs, const int *__restrict__ parents,
     const float *__restrict__ Rs_in, const float *__restrict__ J_in, const float *__restrict__ A_in,
     const float *__restrict__ dcoef, const float *__restrict__ dA, const float *__restrict__ dnewJ,
-    float *__restrict__ dx) {
+    const float *__restrict__ dcam, float *__restrict__ dx) {
   __shared__ PoseLds lds[MPB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.x * MPB + wave;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     for (int e = lane; e < 72; e += 64) L.J[e / 3][e % 3] = J_in[nn * 72 + e];
     for (int e = lane; e < 288; e += 64) L.G[e / 12][e % 12] = A_in[nn * 288 + e];  // G.R = A.R
   }
-  __syncthreads();
+  wave_sync();
   if (live && lane < 24) {
     const int i = lane;
     const float *dAi = dA + nn * 288 + i * 12;
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     for (int c = 0; c < 3; ++c)
       L.dJ[i][c] = -(L.G[i][0 * 4 + c] * dAt[0] + L.G[i][1 * 4 + c] * dAt[1] + L.G[i][2 * 4 + c] * dAt[2]);
   }
-  __syncthreads();
+  wave_sync();
   for (int i = 23; i >= 1; --i) {
     const int p = parents[i];
     float upd = 0.f;
@@ -218,11 +226,11 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
       L.dJ[i][c] += tmp;
       L.dJ[p][c] -= tmp;
     }
-    __syncthreads();
+    wave_sync();
   }
   if (live && lane < 9) L.dR[0][lane] = L.dGR[0][lane];
   if (live && lane >= 16 && lane < 19) L.dJ[0][lane - 16] += L.dGt[0][lane - 16];
-  __syncthreads();
+  wave_sync();
   if (live) {
     float *dxr = dx + nn * x_stride;
     const float *xr = x + nn * x_stride;
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
       for (int e = 0; e < 72; ++e) acc += L.dJ[e / 3][e % 3] * J_dirs[e * 10 + k];
       dxr[num_cam + 72 + k] = acc;
     } else if (lane >= 48 && lane < 48 + num_cam) {
-      dxr[lane - 48] = 0.0f;
+      const int cidx = lane - 48;
+      dxr[cidx] = (dcam && cidx < 4) ? dcam[nn * 4 + cidx] : 0.0f;
     }
   }
 }
@@ -271,15 +280,15 @@ int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B, const float
 
 int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B, const float *J_dirs,
                    const int32_t *parents, const float *Rs, const float *J, const float *A,
-                   const float *dcoef, const float *dA, const float *dJ_transformed, float *dx,
-                   void *stream) {
+                   const float *dcoef, const float *dA, const float *dJ_transformed, const float *dcam,
+                   float *dx, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && num_cam >= 0 && num_cam <= 16 && x_stride >= num_cam + 82,
                 "smplr_pose_bwd: bad sizes B=%d num_cam=%d x_stride=%d", B, num_cam, x_stride);
   if (B == 0) return 0;
   SMPLR_REQUIRE(x && J_dirs && parents && Rs && J && A && dcoef && dA && dx, "smplr_pose_bwd: null pointer");
   hipLaunchKernelGGL(pose_bwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
-                     x, x_stride, num_cam, B, J_dirs, parents, Rs, J, A, dcoef, dA, dJ_transformed, dx);
+                     x, x_stride, num_cam, B, J_dirs, parents, Rs, J, A, dcoef, dA, dJ_transformed, dcam, dx);
   SMPLR_LAUNCH_CHECK("smplr_pose_bwd");
   return 0;
 }

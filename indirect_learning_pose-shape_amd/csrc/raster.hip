@@ -2,45 +2,204 @@
 //
 // Reference: keras_smpl/projects_to_seg.py:34-69 and keras_smpl/projects_to_silhouette.py:20-42.
 // The reference materialises (N, W^2, n_p, 2) tiles per part and takes max_v exp(-m_v d_v);
-// since exp is monotone that is exp(-min_v m_v d_v): a masked nearest-vertex search.
+// exp is monotone, so that is exp(-min_v m_v d_v): a masked nearest-vertex search.
 //
-// Forward: a lane owns one pixel, a workgroup 256 consecutive pixels of one mesh.  The mesh's
-// vertices are first gathered part-major into (u, v, m^2, m) records (`sorted`, each part
-// padded to a multiple of 8 with +inf sentinels), so the pair loop reads wave-uniform records
-// (scalar loads, no LDS, no vector memory) and spends its time on the fp32 VALU:
-// key = m^2 * ((u-c)^2 + (v-r)^2), running minimum per 8-vertex chunk; the winning chunk is
-// re-evaluated once per (pixel, part) to recover the first arg-min, and the score is
-// exp(-m * sqrt(d2)) of that vertex.  Scores and arg-mins are transposed through LDS so the
-// NHWC outputs are written as whole 128-B pixel rows.
+// Segmentation forward = two kernels.
+//  (1) seg_bin_kernel, one workgroup per mesh: splits the part-major vertex list by reach.
+//      In fp32 exp(-x) == 0 for x >= 104, so a vertex with mask m only matters within
+//      104/m pixels.  m > 208 ("local": the invisible vertices, m = 500) reaches at most its
+//      nearest pixel centre -> one (pixel, part, x, vertex) record, counting-sorted by pixel.
+//      m <= 208 ("global": the visible vertices, m = 1) are compacted part-major, in table
+//      order, each part padded to a multiple of 4 with +inf sentinels, as (u, v, m^2, vertex).
+//      This drops the pair count from 2304 x 6879 to 2304 x (#visible ~ 500) per mesh without
+//      changing a single fp32 result.
+//  (2) raster_fwd_kernel: a lane owns one pixel, a workgroup 256 consecutive pixels of one
+//      mesh.  Global records are wave-uniform, so the pair loop reads them with scalar loads
+//      (no LDS, no vector memory) and runs on the fp32 VALU: key = m^2((u-c)^2 + (v-r)^2),
+//      min per group of 4, winning group re-evaluated once per (pixel, part) for the first
+//      arg-min; score = exp(-sqrt(key)).  The pixel's local records are then merged in.  Scores
+//      and arg-mins go through a wave-private LDS tile (16 channels at a time) so the NHWC
+//      outputs are written as contiguous 64-B / 32-B pixel segments.
 //
-// Backward: lanes = (pixel, channel) exactly as the NHWC tensors lie in memory (coalesced,
-// and neighbouring lanes hit different parts, hence different vertices); per-mesh gradient
-// accumulation in LDS (V' x 2 floats) with ds_add_f32, one plain store pass at the end.
+// Backward: lanes = (pixel, channel) exactly as the NHWC tensors lie in memory (coalesced, and
+// the 32 lanes of a pixel hit 31 different parts, hence different vertices); the score is
+// recomputed from the arg-min vertex (no re-read of seg); each workgroup accumulates its pixel
+// range in LDS (V' x 2 floats, ds_add_f32) and flushes the non-zero entries with float atomics.
 #include "common.h"
 
 namespace smplr {
 
-constexpr int CH = SMPLR_CHUNK;   // 8
-constexpr int RT = 256;           // pixels (threads) per block
-constexpr int SLD = 33;           // LDS transpose stride
+constexpr int CH = SMPLR_CHUNK;      // 8: silhouette list padding
+constexpr int RT = 256;              // pixels (threads) per raster block
+constexpr float X_ZERO = 104.0f;     // expf(-x) rounds to 0 in fp32 for x >= 104
+constexpr float M_LOCAL = 208.0f;    // m > 208 => 104/m < 0.5 px: only the nearest pixel centre
+constexpr int GP = 4;                // global-list group size (padding granule)
+constexpr int BIN_T = 1024;
 
-// sorted[n][k] = (u, v, m*m, m) for slot k; pos < 0 -> sentinel (+inf, +inf, 1, 1).
-__global__ __launch_bounds__(256) void seg_prep_kernel(const float *__restrict__ proj,
-                                                       const float *__restrict__ mask,
-                                                       const int *__restrict__ part_pos, int VP, int KP,
-                                                       float4 *__restrict__ sorted) {
-  const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= KP) return;
-  const int pos = part_pos ? part_pos[k] : (k < VP ? k : -1);
-  float4 o;
-  if (pos < 0) {
-    o = make_float4(INFINITY, INFINITY, 1.0f, 1.0f);
-  } else {
-    const float *p = proj + ((size_t)n * VP + pos) * 3;
-    const float m = mask ? mask[(size_t)n * VP + pos] : 1.0f;
-    o = make_float4(p[0], p[1], m * m, m);
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan(int val, int *s_wave /*[BIN_T/64]*/, int *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = val;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
   }
-  sorted[(size_t)n * KP + k] = o;
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < BIN_T / 64; ++w) {
+    const int t = s_wave[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  *total = tot;
+  return base + inc - val;
+}
+
+struct Slot {
+  int cls;      // 0 skip, 1 global, 2 local
+  int pos, pix;
+  float u, v, m, x;
+};
+
+__device__ __forceinline__ Slot classify(const float *__restrict__ pj, const float *__restrict__ mk, int pos,
+                                         int W) {
+  Slot s;
+  s.pos = pos;
+  s.u = pj[pos * 3];
+  s.v = pj[pos * 3 + 1];
+  s.m = mk[pos];
+  s.cls = 1;
+  s.pix = 0;
+  s.x = 0.f;
+  if (s.m > M_LOCAL) {
+    s.cls = 0;
+    const float c = rintf(s.u), r = rintf(s.v);
+    if (c >= 0.0f && c <= (float)(W - 1) && r >= 0.0f && r <= (float)(W - 1)) {
+      const float du = s.u - c, dv = s.v - r;
+      s.x = sqrtf(fmaf(du, du, dv * dv) * (s.m * s.m));
+      if (s.x < X_ZERO) {
+        s.cls = 2;
+        s.pix = (int)r * W + (int)c;
+      }
+    }
+  }
+  return s;
+}
+
+// workspace per mesh: G[Kpad] float4 | goff[P+1] | lstart[npix+1] | lrec[K] uint2
+__global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict__ proj,
+                                                        const float *__restrict__ mask,
+                                                        const int *__restrict__ part_pos,
+                                                        const int *__restrict__ part_off, int P, int K,
+                                                        int VP, int W, int Kpad, float4 *__restrict__ G,
+                                                        int *__restrict__ goff, int *__restrict__ lstart,
+                                                        uint2 *__restrict__ lrec) {
+  extern __shared__ int s_cnt[];   // npix
+  __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int npix = W * W;
+  const float *pj = proj + (size_t)n * VP * 3;
+  const float *mk = mask + (size_t)n * VP;
+  float4 *Gn = G + (size_t)n * Kpad;
+  int *goffn = goff + (size_t)n * (P + 1);
+  int *lstartn = lstart + (size_t)n * (npix + 1);
+  uint2 *lrecn = lrec + (size_t)n * K;
+
+  if (tid <= P) s_poff[tid] = part_off[tid];
+  for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
+  __syncthreads();
+  const int ipt = (K + BIN_T - 1) / BIN_T;
+  const int k0 = tid * ipt, k1 = min(K, k0 + ipt);
+  // pass 1: counts
+  int gcnt = 0;
+  for (int k = k0; k < k1; ++k) {
+    const Slot s = classify(pj, mk, part_pos[k], W);
+    if (s.cls == 1) ++gcnt;
+    else if (s.cls == 2) atomicAdd(&s_cnt[s.pix], 1);
+  }
+  int gtotal;
+  const int gbase = block_excl_scan(gcnt, s_wave, &gtotal);
+  if (tid <= P) s_gstart[tid] = gtotal;   // default for empty trailing parts; ordered by the scan's barriers
+  // counting sort offsets over pixels
+  {
+    const int ept = (npix + BIN_T - 1) / BIN_T;
+    const int e0 = tid * ept, e1 = min(npix, e0 + ept);
+    int loc = 0;
+    for (int e = e0; e < e1; ++e) loc += s_cnt[e];
+    int ltotal;
+    int run = block_excl_scan(loc, s_wave, &ltotal);
+    for (int e = e0; e < e1; ++e) {
+      const int c = s_cnt[e];
+      s_cnt[e] = run;            // becomes the placement cursor
+      lstartn[e] = run;
+      run += c;
+    }
+    if (tid == 0) lstartn[npix] = ltotal;
+  }
+  // pass 2: global prefix at part starts
+  {
+    int p = 0;
+    if (k0 < k1) {
+      int lo = 0, hi = P;        // largest p with poff[p] <= k0
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_poff[mid] <= k0) lo = mid; else hi = mid;
+      }
+      p = lo;
+    }
+    int run = gbase;
+    for (int k = k0; k < k1; ++k) {
+      while (k >= s_poff[p + 1]) ++p;
+      for (int pp = p; pp >= 0 && s_poff[pp] == k; --pp) s_gstart[pp] = run;   // (also empty parts)
+      const Slot s = classify(pj, mk, part_pos[k], W);
+      if (s.cls == 1) ++run;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int p = 0; p < P; ++p) {
+      s_gpad[p] = acc;
+      goffn[p] = acc;
+      acc += (s_gstart[p + 1] - s_gstart[p] + GP - 1) / GP * GP;
+    }
+    s_gpad[P] = acc;
+    goffn[P] = acc;
+  }
+  __syncthreads();
+  // pass 3: placement
+  {
+    int p = 0;
+    if (k0 < k1) {
+      int lo = 0, hi = P;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_poff[mid] <= k0) lo = mid; else hi = mid;
+      }
+      p = lo;
+    }
+    int run = gbase;
+    for (int k = k0; k < k1; ++k) {
+      while (k >= s_poff[p + 1]) ++p;
+      const Slot s = classify(pj, mk, part_pos[k], W);
+      if (s.cls == 1) {
+        Gn[s_gpad[p] + (run - s_gstart[p])] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
+        ++run;
+      } else if (s.cls == 2) {
+        const int dst = atomicAdd(&s_cnt[s.pix], 1);
+        lrecn[dst] = make_uint2(__float_as_uint(s.x), ((unsigned)s.pos << 8) | (unsigned)p);
+      }
+    }
+  }
+  // sentinels in the padding
+  if (tid < P) {
+    const int cnt = s_gstart[tid + 1] - s_gstart[tid];
+    for (int i = s_gpad[tid] + cnt; i < s_gpad[tid + 1]; ++i)
+      Gn[i] = make_float4(INFINITY, INFINITY, 1.0f, __int_as_float(-1));
+  }
 }
 
 __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
@@ -48,134 +207,206 @@ __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
   return fmaf(du, du, dv * dv) * a.z;
 }
 
-// SILH = false: P parts, outputs seg (B,W,W,P+1) + arg (B,W,W,32) int16.
-// SILH = true : one part = all vertices, outputs silh (B,W,W,2) + arg (B,W,W) int32.
-template <bool SILH>
-__global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict__ sorted,
-                                                        const int *__restrict__ part_pos,
-                                                        const int *__restrict__ part_off, int P, int KP,
-                                                        int W, float *__restrict__ out,
-                                                        void *__restrict__ arg_out) {
-  __shared__ float sS[SILH ? 1 : (RT / 64) * 64 * SLD];
-  __shared__ short sA[SILH ? 1 : (RT / 64) * 64 * SLD];
+constexpr int HC = 16;    // channels per half
+constexpr int TLD = 17;   // tile row stride
+
+__global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict__ G,
+                                                        const int *__restrict__ goff,
+                                                        const int *__restrict__ lstart,
+                                                        const uint2 *__restrict__ lrec, int P, int K,
+                                                        int Kpad, int W, float *__restrict__ seg,
+                                                        short *__restrict__ arg) {
+  __shared__ float sS[RT * TLD];
+  __shared__ short sA[RT * TLD];
   const int n = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int q = blockIdx.x * RT + tid;
   const int npix = W * W;
+  const int q = blockIdx.x * RT + tid;
   const bool live = q < npix;
-  const int r = q / W, c = q - r * W;
+  const int qc = live ? q : npix - 1;
+  const int r = qc / W, c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
-  const float4 *S = sorted + (size_t)n * KP;
+  const float4 *Gn = G + (size_t)n * Kpad;
+  const int *goffn = goff + (size_t)n * (P + 1);
   const int C = P + 1;
+  const int l0 = lstart[(size_t)n * (npix + 1) + qc], l1 = lstart[(size_t)n * (npix + 1) + qc + 1];
+  const uint2 *lrecn = lrec + (size_t)n * K;
+  float *myS = &sS[tid * TLD];
+  short *myA = &sA[tid * TLD];
 
   float sum = 0.0f;
-  for (int p = 0; p < P; ++p) {
-    const int beg = SILH ? 0 : part_off[p], end = SILH ? KP : part_off[p + 1];
-    float best = INFINITY;
-    int bestk = beg;
-    for (int k = beg; k < end; k += CH) {
-      float cm = pair_key(S[k], fc, fr);
+  for (int half = 1; half >= 0; --half) {
+    const int ch0 = half * HC;
+    for (int j = 0; j < HC; ++j) {
+      const int ch = ch0 + j;
+      if (ch == 0 || ch >= C) { myS[j] = 0.0f; myA[j] = -1; continue; }
+      const int p = ch - 1;
+      const int beg = goffn[p], end = goffn[p + 1];      // wave-uniform
+      float best = INFINITY;
+      int bestk = beg;
+      for (int k = beg; k < end; k += GP) {
+        const float k0 = pair_key(Gn[k], fc, fr), k1 = pair_key(Gn[k + 1], fc, fr);
+        const float k2 = pair_key(Gn[k + 2], fc, fr), k3 = pair_key(Gn[k + 3], fc, fr);
+        const float cm = fminf(fminf(k0, k1), fminf(k2, k3));
+        if (cm < best) { best = cm; bestk = k; }
+      }
+      float score = 0.0f;
+      int pos = -1;
+      if (best < INFINITY) {
 #pragma unroll
-      for (int j = 1; j < CH; ++j) cm = fminf(cm, pair_key(S[k + j], fc, fr));
-      if (cm < best) { best = cm; bestk = k; }
+        for (int jj = GP - 1; jj >= 0; --jj) {
+          const float4 a = Gn[bestk + jj];
+          if (pair_key(a, fc, fr) == best) pos = __float_as_int(a.w);
+        }
+        score = expf(-sqrtf(best));
+      }
+      myS[j] = score;
+      myA[j] = (short)pos;
     }
-    // resolve the first arg-min inside the winning chunk (per-lane addresses: vector loads)
-    int sel = 0;
-    float4 win = make_float4(INFINITY, INFINITY, 1.0f, 1.0f);
-    if (beg < end) {
-#pragma unroll
-      for (int j = CH - 1; j >= 0; --j) {
-        const float4 a = S[bestk + j];
-        if (pair_key(a, fc, fr) == best) { sel = j; win = a; }
+    // merge this pixel's local records (invisible vertices that round to this pixel)
+    for (int i = l0; i < l1; ++i) {
+      const uint2 rec = lrecn[i];
+      const int ch = 1 + (int)(rec.y & 0xFFu);
+      if (ch >= ch0 && ch < ch0 + HC) {
+        const float sc = expf(-__uint_as_float(rec.x));
+        const int j = ch - ch0, pos = (int)(rec.y >> 8);
+        const float cur = myS[j];
+        if (sc > cur || (sc == cur && sc > 0.0f && (myA[j] < 0 || pos < (int)myA[j]))) {
+          myS[j] = sc;
+          myA[j] = (short)pos;
+        }
       }
     }
-    const float du = win.x - fc, dv = win.y - fr;
-    const float d = sqrtf(fmaf(du, du, dv * dv));
-    int pos = SILH ? (bestk + sel) : part_pos[bestk + sel];
-    float score;
-    if (SILH) {
-      score = expf(-d / 1.2f);
-    } else {
-      score = expf(-(d * win.w));
+    for (int j = 0; j < HC; ++j) sum += myS[j];          // slot of channel 0 holds 0 here
+    if (half == 0) {
+      myS[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);     // background (:61-64)
+      myA[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;     // clip pass-through gate
     }
-    if (!(best < INFINITY)) { score = 0.0f; pos = 0; }   // empty part / all sentinels / NaN
-    if (SILH) {
-      if (live) {
-        const size_t o = ((size_t)n * W + (W - 1 - r)) * W + c;   // rows flipped (:42)
-        out[o * 2 + 0] = 1.0f - score;
-        out[o * 2 + 1] = score;
-        reinterpret_cast<int *>(arg_out)[o] = pos;
+    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): tile writes done
+    __builtin_amdgcn_wave_barrier();
+    // write this half: 64 pixels x 16 channels; lane -> (pixel, 4-channel group)
+    const int q0 = blockIdx.x * RT + wave * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int e = it * 64 + lane;
+      const int pl = e >> 2, c4 = (e & 3) * 4;
+      const int qq = q0 + pl;
+      if (qq < npix) {
+        const int rr = qq / W, cc = qq - rr * W;
+        const size_t o = ((size_t)n * W + (W - 1 - rr)) * W + cc;     // rows flipped (:68)
+        const float *ts = &sS[(wave * 64 + pl) * TLD + c4];
+        const short *ta = &sA[(wave * 64 + pl) * TLD + c4];
+        float *so = seg + o * C + ch0 + c4;
+        if (ch0 + c4 + 3 < C && (C & 3) == 0) {
+          *reinterpret_cast<float4 *>(so) = make_float4(ts[0], ts[1], ts[2], ts[3]);
+        } else {
+          for (int t = 0; t < 4; ++t)
+            if (ch0 + c4 + t < C) so[t] = ts[t];
+        }
+        short4 av;
+        av.x = ta[0]; av.y = ta[1]; av.z = ta[2]; av.w = ta[3];
+        *reinterpret_cast<short4 *>(arg + o * 32 + ch0 + c4) = av;
       }
-    } else {
-      sum += score;
-      sS[(wave * 64 + lane) * SLD + 1 + p] = score;
-      sA[(wave * 64 + lane) * SLD + p] = (short)pos;
     }
-  }
-  if (SILH) return;
-  // background = 1 - clip(sum, 0, 1) (:61-64); gate = clip passes gradient (0 <= sum <= 1)
-  sS[(wave * 64 + lane) * SLD + 0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);
-  for (int p = P; p < 31; ++p) sA[(wave * 64 + lane) * SLD + p] = 0;
-  sA[(wave * 64 + lane) * SLD + 31] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;
-  // wave-private tiles: no block barrier needed, but order LDS writes before the reads
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-  __builtin_amdgcn_wave_barrier();
-  const int q0 = blockIdx.x * RT + wave * 64;
-  short *arg = reinterpret_cast<short *>(arg_out);
-  for (int e = lane; e < 64 * 32; e += 64) {
-    const int pl = e >> 5, ch = e & 31;
-    const int qq = q0 + pl;
-    if (qq < npix) {
-      const int rr = qq / W, cc = qq - rr * W;
-      const size_t o = ((size_t)n * W + (W - 1 - rr)) * W + cc;   // rows flipped (:68)
-      if (ch < C) out[o * C + ch] = sS[(wave * 64 + pl) * SLD + ch];
-      arg[o * 32 + ch] = sA[(wave * 64 + pl) * SLD + ch];
-    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-// dproj (B,VP,3); one block per mesh, LDS accumulators acc[VP*2].
+// ------------------------------------------------------------------------------------------------
+// dproj (B,VP,3) must be zero on entry (the launcher memsets it).  grid (nsplit, B).
 __global__ __launch_bounds__(1024) void seg_bwd_kernel(const float *__restrict__ dseg,
-                                                       const float *__restrict__ seg,
                                                        const short *__restrict__ arg,
                                                        const float *__restrict__ proj,
                                                        const float *__restrict__ mask, int VP, int W, int P,
                                                        float *__restrict__ dproj) {
   extern __shared__ float acc[];   // VP*2
-  const int n = blockIdx.x, tid = threadIdx.x;
+  const int n = blockIdx.y, tid = threadIdx.x;
   for (int i = tid; i < VP * 2; i += 1024) acc[i] = 0.0f;
   __syncthreads();
   const int C = P + 1, npix = W * W;
   const float *pj = proj + (size_t)n * VP * 3;
   const float *mk = mask + (size_t)n * VP;
-  // element e = (pixel, slot) over 32 slots per pixel; slot s<P is part s (channel s+1)
-  for (int e = tid; e < npix * 32; e += 1024) {
-    const int o = e >> 5, s = e & 31;        // o = output pixel index (flipped row-major)
+  const int per = (npix + gridDim.x - 1) / gridDim.x;
+  const int o_beg = blockIdx.x * per, o_end = min(npix, o_beg + per);
+  for (int e = o_beg * 32 + tid; e < o_end * 32; e += 1024) {
+    const int o = e >> 5, ch = e & 31;       // o = output pixel index (flipped row-major)
     const size_t po = (size_t)n * npix + o;
-    const short a = arg[po * 32 + s];
-    const int gate = __shfl((int)a, 31, 32);     // slot 31 of this pixel (32-lane groups)
-    if (s < P) {
-      const float g0 = dseg[po * C];
-      const float g = dseg[po * C + 1 + s] - (gate ? g0 : 0.0f);
-      const float sc = seg[po * C + 1 + s];
+    const int a = arg[po * 32 + ch];
+    const float gv = (ch < C) ? dseg[po * C + ch] : 0.0f;
+    const int gate = __shfl(a, 0, 32);       // channel-0 lane of this pixel
+    const float g0 = __shfl(gv, 0, 32);
+    if (ch >= 1 && ch < C && a >= 0) {
+      const float g = gv - (gate ? g0 : 0.0f);
       const int ro = o / W, cc = o - ro * W;
       const float fr = (float)(W - 1 - ro), fc = (float)cc;
-      const int v = (unsigned short)a;
-      const float du = pj[v * 3] - fc, dv = pj[v * 3 + 1] - fr;
+      const float du = pj[a * 3] - fc, dv = pj[a * 3 + 1] - fr;
+      const float m = mk[a];
       const float d = sqrtf(fmaf(du, du, dv * dv));
-      const float k = -g * sc * mk[v];
+      const float sc = expf(-(d * m));
+      const float k = -g * sc * m;
       if (d > 0.0f && k != 0.0f) {
         const float kk = k / d;
-        atomicAdd(&acc[v * 2], kk * du);
-        atomicAdd(&acc[v * 2 + 1], kk * dv);
+        atomicAdd(&acc[a * 2], kk * du);
+        atomicAdd(&acc[a * 2 + 1], kk * dv);
       }
     }
   }
   __syncthreads();
   float *o = dproj + (size_t)n * VP * 3;
-  for (int i = tid; i < VP * 3; i += 1024) {
-    const int v = i / 3, c = i - v * 3;
-    o[i] = (c < 2) ? acc[v * 2 + c] : 0.0f;
+  for (int i = tid; i < VP * 2; i += 1024) {
+    const float v = acc[i];
+    if (v != 0.0f) atomicAdd(&o[(i >> 1) * 3 + (i & 1)], v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Silhouette: every vertex is "global" with weight 1/1.2 (no mask): brute force over all of them.
+__global__ __launch_bounds__(256) void silh_prep_kernel(const float *__restrict__ proj, int VP, int KP,
+                                                        float4 *__restrict__ sorted) {
+  const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= KP) return;
+  float4 o = make_float4(INFINITY, INFINITY, 1.0f, __int_as_float(-1));
+  if (k < VP) {
+    const float *p = proj + ((size_t)n * VP + k) * 3;
+    o = make_float4(p[0], p[1], 1.0f, __int_as_float(k));
+  }
+  sorted[(size_t)n * KP + k] = o;
+}
+
+__global__ __launch_bounds__(RT) void silh_fwd_kernel(const float4 *__restrict__ sorted, int KP, int W,
+                                                      float *__restrict__ out, int *__restrict__ arg_out) {
+  const int n = blockIdx.y;
+  const int q = blockIdx.x * RT + threadIdx.x;
+  const int npix = W * W;
+  const bool live = q < npix;
+  const int qc = live ? q : npix - 1;
+  const int r = qc / W, c = qc - r * W;
+  const float fc = (float)c, fr = (float)r;
+  const float4 *S = sorted + (size_t)n * KP;
+  float best = INFINITY;
+  int bestk = 0;
+  for (int k = 0; k < KP; k += CH) {
+    float cm = pair_key(S[k], fc, fr);
+#pragma unroll
+    for (int j = 1; j < CH; ++j) cm = fminf(cm, pair_key(S[k + j], fc, fr));
+    if (cm < best) { best = cm; bestk = k; }
+  }
+  int pos = -1;
+  float score = 0.0f;
+  if (best < INFINITY) {
+#pragma unroll
+    for (int j = CH - 1; j >= 0; --j) {
+      const float4 a = S[bestk + j];
+      if (pair_key(a, fc, fr) == best) pos = __float_as_int(a.w);
+    }
+    score = expf(-sqrtf(best) / 1.2f);
+  }
+  if (live) {
+    const size_t o = ((size_t)n * W + (W - 1 - r)) * W + c;   // rows flipped (:42)
+    out[o * 2 + 0] = 1.0f - score;
+    out[o * 2 + 1] = score;
+    arg_out[o] = pos;
   }
 }
 
@@ -195,6 +426,7 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
     const float g = dsilh[po * 2 + 1] - dsilh[po * 2];
     const float sc = silh[po * 2 + 1];
     const int v = arg[po];
+    if (v < 0) continue;
     const int ro = o / W, cc = o - ro * W;
     const float fr = (float)(W - 1 - ro), fc = (float)cc;
     const float du = pj[v * 3] - fc, dv = pj[v * 3 + 1] - fr;
@@ -225,43 +457,79 @@ static int set_lds_attr(const void *fn, size_t lds) {
   return 0;
 }
 
+struct SegWs {
+  size_t g_off, goff_off, lstart_off, lrec_off, total;
+  int Kpad;
+};
+
+static SegWs seg_ws_layout(int B, int W, int P, int K) {
+  SegWs w;
+  w.Kpad = K + (GP - 1) * P;
+  w.Kpad = (w.Kpad + 3) / 4 * 4;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  w.g_off = take((size_t)B * w.Kpad * sizeof(float4));
+  w.goff_off = take((size_t)B * (P + 1) * sizeof(int));
+  w.lstart_off = take((size_t)B * ((size_t)W * W + 1) * sizeof(int));
+  w.lrec_off = take((size_t)B * K * sizeof(uint2));
+  w.total = off;
+  return w;
+}
+
 }  // namespace smplr
 
 extern "C" {
 
+size_t smplr_seg_workspace(int B, int VP, int W, int P, int K) {
+  if (B <= 0 || VP <= 0 || W <= 0 || P <= 0 || K <= 0) return 0;
+  return smplr::seg_ws_layout(B, W, P, K).total;
+}
+
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, const int32_t *part_pos,
-                  const int32_t *part_off, int P, int KP, float *sorted, float *seg, int16_t *arg,
+                  const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,
                   void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 1024 && P >= 1 && P <= 31 && KP > 0 &&
-                    KP % CH == 0,
-                "smplr_seg_fwd: bad sizes B=%d VP=%d W=%d P=%d KP=%d", B, VP, W, P, KP);
+  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0,
+                "smplr_seg_fwd: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", B, VP, W, P, K);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(proj && mask && part_pos && part_off && sorted && seg && arg, "smplr_seg_fwd: null pointer");
+  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg, "smplr_seg_fwd: null pointer");
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(seg_prep_kernel, dim3((KP + 255) / 256, B), dim3(256), 0, st, proj, mask, part_pos, VP,
-                     KP, reinterpret_cast<float4 *>(sorted));
-  SMPLR_LAUNCH_CHECK("smplr_seg_fwd(prep)");
-  hipLaunchKernelGGL(raster_fwd_kernel<false>, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st,
-                     reinterpret_cast<const float4 *>(sorted), part_pos, part_off, P, KP, W, seg,
-                     reinterpret_cast<void *>(arg));
+  const SegWs ws = seg_ws_layout(B, W, P, K);
+  char *base = reinterpret_cast<char *>(workspace);
+  float4 *G = reinterpret_cast<float4 *>(base + ws.g_off);
+  int *goff = reinterpret_cast<int *>(base + ws.goff_off);
+  int *lstart = reinterpret_cast<int *>(base + ws.lstart_off);
+  uint2 *lrec = reinterpret_cast<uint2 *>(base + ws.lrec_off);
+  const size_t lds = (size_t)W * W * sizeof(int);
+  int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(seg_bin_kernel, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K, VP, W,
+                     ws.Kpad, G, goff, lstart, lrec);
+  SMPLR_LAUNCH_CHECK("smplr_seg_fwd(bin)");
+  hipLaunchKernelGGL(raster_fwd_kernel, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st, G, goff, lstart, lrec, P,
+                     K, ws.Kpad, W, seg, reinterpret_cast<short *>(arg));
   SMPLR_LAUNCH_CHECK("smplr_seg_fwd");
   return 0;
 }
 
-int smplr_seg_bwd(const float *dseg, const float *seg, const int16_t *arg, const float *proj,
-                  const float *mask, int B, int VP, int W, int P, float *dproj, void *stream) {
+int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *proj, const float *mask, int B, int VP,
+                  int W, int P, float *dproj, void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 1024 && P >= 1 && P <= 31,
+  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31,
                 "smplr_seg_bwd: bad sizes B=%d VP=%d W=%d P=%d", B, VP, W, P);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(dseg && seg && arg && proj && mask && dproj, "smplr_seg_bwd: null pointer");
+  SMPLR_REQUIRE(dseg && arg && proj && mask && dproj, "smplr_seg_bwd: null pointer");
   const size_t lds = (size_t)VP * 2 * sizeof(float);
   SMPLR_REQUIRE(lds <= 150 * 1024, "smplr_seg_bwd: VP=%d needs %zu B of LDS", VP, lds);
   int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel), lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(seg_bwd_kernel, dim3(B), dim3(1024), lds, as_stream(stream), dseg, seg,
-                     reinterpret_cast<const short *>(arg), proj, mask, VP, W, P, dproj);
+  hipStream_t st = as_stream(stream);
+  SMPLR_HIP(hipMemsetAsync(dproj, 0, (size_t)B * VP * 3 * sizeof(float), st));
+  int nsplit = (512 + B - 1) / B;          // ~2 blocks per CU chip-wide
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 16) nsplit = 16;
+  hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(1024), lds, st, dseg, reinterpret_cast<const short *>(arg),
+                     proj, mask, VP, W, P, dproj);
   SMPLR_LAUNCH_CHECK("smplr_seg_bwd");
   return 0;
 }
@@ -280,12 +548,11 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
   SMPLR_REQUIRE(proj && silh && arg && workspace, "smplr_silh_fwd: null pointer");
   const int KP = (VP + CH - 1) / CH * CH;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(seg_prep_kernel, dim3((KP + 255) / 256, B), dim3(256), 0, st, proj,
-                     (const float *)nullptr, (const int *)nullptr, VP, KP, reinterpret_cast<float4 *>(workspace));
+  hipLaunchKernelGGL(silh_prep_kernel, dim3((KP + 255) / 256, B), dim3(256), 0, st, proj, VP, KP,
+                     reinterpret_cast<float4 *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_silh_fwd(prep)");
-  hipLaunchKernelGGL(raster_fwd_kernel<true>, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st,
-                     reinterpret_cast<const float4 *>(workspace), (const int *)nullptr, (const int *)nullptr, 1,
-                     KP, W, silh, reinterpret_cast<void *>(arg));
+  hipLaunchKernelGGL(silh_fwd_kernel, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st,
+                     reinterpret_cast<const float4 *>(workspace), KP, W, silh, arg);
   SMPLR_LAUNCH_CHECK("smplr_silh_fwd");
   return 0;
 }

@@ -18,7 +18,8 @@ namespace smplr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SK_MB = 4;       // meshes per thread in the forward (weights stay in registers)
-constexpr int SKB_T = 512;     // backward block: 512 vertices (8 waves)
+constexpr int SKB_T = 256;     // backward block: 256 vertices (4 waves)
+constexpr int SKB_WLD = 25;    // LDS stride of a vertex' 24 weights (odd: conflict-free)
 
 __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__ v_posed,
                                                        const float *__restrict__ lbs,
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
   }
 }
 
-// One block = one mesh x 512 vertices.  part layout per (mesh, block): 288 dA + 4 dcam floats.
+// One block = one mesh x 256 vertices.  part layout per (mesh, block): 288 dA + 4 dcam floats.
 constexpr int SKB_PART = 292;
 
 __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   __shared__ float sG[SKB_T][4];    // g (3) per vertex
   __shared__ float sP[SKB_T][4];    // [v_posed;1]
   __shared__ float sRed[SKB_T / 64][SKB_PART];
+  __shared__ float sW[SKB_T * SKB_WLD];
   const int n = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int v = blockIdx.x * SKB_T + tid;
@@ -130,6 +132,8 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     o[1] = T[1] * g0 + T[5] * g1 + T[9] * g2;
     o[2] = T[2] * g0 + T[6] * g1 + T[10] * g2;
   }
+#pragma unroll
+  for (int j = 0; j < 24; ++j) sW[tid * SKB_WLD + j] = w[j];
   sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
   sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
   __syncthreads();
@@ -138,16 +142,12 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   const int li = lane & 15, lk = lane >> 4;
   const int cr = li >> 2, cc = li & 3;   // component j = li = r*4+c  (valid for li < 12)
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const int vbase = blockIdx.x * SKB_T + wave * 64;
 #pragma unroll 4
   for (int s = 0; s < 16; ++s) {
     const int k = s * 4 + lk;                 // vertex within the wave's 64
-    int vk = vbase + k;
-    vk = vk < V ? vk : V - 1;                 // tail: g = 0 there, any finite weight is fine
-    const float *wk = lbs + (size_t)vk * 24;
-    const float a0 = wk[li];
-    const float a1 = (li < 8) ? wk[16 + li] : 0.0f;
-    const int t = wave * 64 + k;
+    const int t = wave * 64 + k;              // tail vertices carry g = 0 and finite (clamped) weights
+    const float a0 = sW[t * SKB_WLD + li];
+    const float a1 = (li < 8) ? sW[t * SKB_WLD + 16 + li] : 0.0f;
     const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
@@ -166,11 +166,11 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
   }
   __syncthreads();
-  if (tid < SKB_PART) {
+  for (int e = tid; e < SKB_PART; e += SKB_T) {
     float acc = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][tid];
-    part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + tid] = acc;
+    for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
+    part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
   }
 }
 

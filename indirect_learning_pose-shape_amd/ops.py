@@ -32,6 +32,7 @@ class SMPLConstants:
     V: int
     v_template: torch.Tensor    # (3V,)
     blend: torch.Tensor         # (220, 3V): rows 0..9 shapedirs, 10..216 posedirs, 217..219 zero
+    blend_t: torch.Tensor       # (3V, 224): blend transposed, rows zero-padded (backward GEMM)
     J_template: torch.Tensor    # (24,3)   = J_regressor @ v_template
     J_dirs: torch.Tensor        # (24,3,10) = J_regressor @ shapedirs
     lbs_weights: torch.Tensor   # (V,24)
@@ -47,6 +48,8 @@ class SMPLConstants:
         blend = np.zeros((KPAD, 3 * V), np.float64)
         blend[:10] = sd
         blend[10:217] = pd
+        blend_t = np.zeros((3 * V, 224), np.float64)
+        blend_t[:, :KPAD] = blend.T
         Jreg = np.asarray(model.J_regressor, np.float64)                    # (24,V)
         J_template = Jreg @ np.asarray(model.v_template, np.float64)        # (24,3)
         J_dirs = np.einsum("jv,vck->jck", Jreg, np.asarray(model.shapedirs, np.float64))
@@ -59,18 +62,18 @@ class SMPLConstants:
             jr = f32(jr)
         return SMPLConstants(
             V=V, v_template=f32(np.asarray(model.v_template).reshape(-1)), blend=f32(blend),
-            J_template=f32(J_template), J_dirs=f32(J_dirs), lbs_weights=f32(model.weights),
+            blend_t=f32(blend_t), J_template=f32(J_template), J_dirs=f32(J_dirs), lbs_weights=f32(model.weights),
             parents=torch.as_tensor(np.asarray(model.parents, np.int32)).to(device),
             joint_regressor=jr)
 
 
 @dataclass
 class PartTable:
-    """Padded part-major vertex positions for the rasteriser (projects_to_seg.py:18-24,36-37)."""
+    """Part-major vertex positions for the rasteriser (projects_to_seg.py:18-24,36-37)."""
     P: int
-    KP: int
-    part_pos: torch.Tensor   # (KP,) int32, -1 padded
-    part_off: torch.Tensor   # (P+1,) int32, multiples of CHUNK
+    K: int
+    part_pos: torch.Tensor   # (K,) int32 positions into the (strided) vertex list
+    part_off: torch.Tensor   # (P+1,) int32 CSR offsets
     VP: int
 
 
@@ -80,18 +83,12 @@ _part_tables = {}
 def build_part_table(ids, off, vertex_sampling, num_verts, device) -> PartTable:
     vs = 1 if vertex_sampling in (None, 1) else int(vertex_sampling)
     P = len(off) - 1
-    pos_list, poff = [], [0]
-    for p in range(P):
-        pos = (np.asarray(ids[off[p]:off[p + 1]], np.int64) // vs).astype(np.int32)
-        pad = (-len(pos)) % CHUNK
-        pos_list.append(np.concatenate([pos, np.full(pad, -1, np.int32)]))
-        poff.append(poff[-1] + len(pos) + pad)
-    part_pos = np.concatenate(pos_list).astype(np.int32)
+    part_pos = (np.asarray(ids, np.int64) // vs).astype(np.int32)          # :36-37
     VP = (num_verts + vs - 1) // vs
-    assert part_pos.max() < VP
-    return PartTable(P=P, KP=int(poff[-1]),
+    assert part_pos.min() >= 0 and part_pos.max() < VP and int(off[-1]) == len(part_pos)
+    return PartTable(P=P, K=int(len(part_pos)),
                      part_pos=torch.as_tensor(part_pos).to(device),
-                     part_off=torch.as_tensor(np.asarray(poff, np.int32)).to(device), VP=VP)
+                     part_off=torch.as_tensor(np.asarray(off, np.int32)).to(device), VP=VP)
 
 
 def get_part_table(vertex_sampling, device, num_verts=6890) -> PartTable:
@@ -160,16 +157,14 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
                              ptr(dv_posed), ptr(dA), ptr(dcam), ptr(ws), stream()), "smplr_skin_bwd")
     dcoef = _empty((B, KPAD), x)
     ws2 = _workspace(lib.smplr_blend_bwd_workspace(B, 3 * c.V), x)
-    check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend), B, 3 * c.V, ptr(dcoef), ptr(ws2), stream()),
+    check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend_t), B, 3 * c.V, ptr(dcoef), ptr(ws2), stream()),
           "smplr_blend_bwd")
     dx = _empty(tuple(x.shape), x)
     if x.shape[1] > num_cam + 82:
         dx.zero_()
     check(lib.smplr_pose_bwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_dirs), ptr(c.parents), ptr(Rs),
-                             ptr(J), ptr(A), ptr(dcoef), ptr(dA), ptr(dJt), ptr(dx), stream()),
+                             ptr(J), ptr(A), ptr(dcoef), ptr(dA), ptr(dJt), ptr(dcam), ptr(dx), stream()),
           "smplr_pose_bwd")
-    if dcam is not None:
-        dx[:, :4] = dcam
     return dx
 
 
@@ -191,19 +186,19 @@ def _seg_fwd(proj, mask, W, pt: PartTable):
     B, VP = proj.shape[0], proj.shape[1]
     if VP != pt.VP:
         raise RuntimeError("projects has %d vertices but the part table expects %d" % (VP, pt.VP))
-    srt = _empty((B, pt.KP, 4), proj)
+    ws = _workspace(lib.smplr_seg_workspace(B, VP, W, pt.P, pt.K), proj)
     seg = _empty((B, W, W, pt.P + 1), proj)
     arg = _empty((B, W, W, 32), proj, torch.int16)
     check(lib.smplr_seg_fwd(ptr(proj), ptr(mask), B, VP, W, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
-                            pt.KP, ptr(srt), ptr(seg), ptr(arg), stream()), "smplr_seg_fwd")
+                            pt.K, ptr(ws), ptr(seg), ptr(arg), stream()), "smplr_seg_fwd")
     return seg, arg
 
 
-def _seg_bwd(dseg, seg, arg, proj, mask, W, pt: PartTable):
+def _seg_bwd(dseg, arg, proj, mask, W, pt: PartTable):
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
     dproj = _empty((B, VP, 3), proj)
-    check(lib.smplr_seg_bwd(ptr(dseg), ptr(seg), ptr(arg), ptr(proj), ptr(mask), B, VP, W, pt.P,
+    check(lib.smplr_seg_bwd(ptr(dseg), ptr(arg), ptr(proj), ptr(mask), B, VP, W, pt.P,
                             ptr(dproj), stream()), "smplr_seg_bwd")
     return dproj
 
@@ -293,15 +288,15 @@ class SegRasterFn(torch.autograd.Function):
         mask = require_cuda(mask, "mask_vals")
         seg, arg = _seg_fwd(proj, mask, int(img_wh), pt)
         ctx.W, ctx.pt = int(img_wh), pt
-        ctx.save_for_backward(proj, mask, seg, arg)
+        ctx.save_for_backward(proj, mask, arg)
         ctx.mark_non_differentiable(arg)
         return seg, arg
 
     @staticmethod
     def backward(ctx, dseg, _darg):
-        proj, mask, seg, arg = ctx.saved_tensors
+        proj, mask, arg = ctx.saved_tensors
         dseg = require_cuda(dseg, "dseg")
-        return _seg_bwd(dseg, seg, arg, proj, mask, ctx.W, ctx.pt), None, None, None
+        return _seg_bwd(dseg, arg, proj, mask, ctx.W, ctx.pt), None, None, None
 
 
 class SilhRasterFn(torch.autograd.Function):
@@ -347,16 +342,16 @@ class DecoderFn(torch.autograd.Function):
         else:
             silh = sarg = torch.empty(0, device=x.device)
         ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, with_silh
-        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, mask, seg, arg, silh, sarg)
+        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, mask, arg, silh, sarg)
         ctx.mark_non_differentiable(mask)
         return verts, proj, mask, seg, silh, Jt
 
     @staticmethod
     def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
-        x, Rs, J, A, v_posed, proj, mask, seg, arg, silh, sarg = ctx.saved_tensors
+        x, Rs, J, A, v_posed, proj, mask, arg, silh, sarg = ctx.saved_tensors
         dproj = None
         if dseg is not None:
-            dproj = _seg_bwd(require_cuda(dseg, "dseg"), seg, arg, proj, mask, ctx.W, ctx.pt)
+            dproj = _seg_bwd(require_cuda(dseg, "dseg"), arg, proj, mask, ctx.W, ctx.pt)
         if ctx.with_silh and dsilh is not None:
             d2 = _silh_bwd(require_cuda(dsilh, "dsilh"), silh, sarg, proj, ctx.W)
             dproj = d2 if dproj is None else dproj + d2

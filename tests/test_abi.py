@@ -42,7 +42,7 @@ def test_ctypes_table_matches_header():
     rc = lib.smplr_visibility(None, 1, 6890, 0, 1, None, None)
     assert rc == -1 and b"grid_wh" in lib.smplr_last_error()
     assert lib.smplr_blend_bwd_workspace(128, 20670) > 0
-    assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 14 * 292 * 4
+    assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 27 * 292 * 4
 
 
 def test_argument_counts_match_header():

@@ -15,20 +15,16 @@ def test_part_tables(part_tables):
     assert np.diff(part_tables[1][1]).min() == 45 and np.diff(part_tables[1][1]).max() == 710
 
 
-def test_padded_part_table():
+def test_device_part_table():
     from ilps_amd import ops
     from ilps_amd.smpl_model import load_part_tables
     for vs in (1, 2, 5):
         ids, off = load_part_tables(vs)
         pt = ops.build_part_table(ids, off, vs, 6890, "cpu")
-        po, pp = pt.part_off.numpy(), pt.part_pos.numpy()
-        assert pt.P == 31 and np.all(po % 8 == 0) and po[-1] == pt.KP == len(pp)
-        assert pt.VP == (6890 + vs - 1) // vs
-        for p in range(31):
-            seg = pp[po[p]:po[p + 1]]
-            real = seg[seg >= 0]
-            assert np.array_equal(real, ids[off[p]:off[p + 1]] // vs)
-            assert np.all(seg[len(real):] == -1) and len(seg) - len(real) < 8
+        assert pt.P == 31 and pt.K == len(ids) and pt.VP == (6890 + vs - 1) // vs
+        assert np.array_equal(pt.part_off.numpy(), off)
+        assert np.array_equal(pt.part_pos.numpy(), ids // vs)        # projects_to_seg.py:36-37
+        assert len(np.unique(pt.part_pos.numpy())) == pt.K            # still disjoint after // vs
 
 
 def test_synthetic_model(smpl_model):
