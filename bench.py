@@ -76,11 +76,11 @@ def stage_breakdown(x, consts, pt, W, reps=20):
     res["skin_fwd"] = event_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
     mask = ops.visibility(proj)
     res["visibility"] = event_time_ms(lambda: ops.visibility(proj), reps, st)
-    seg, arg = ops._seg_fwd(proj, mask, W, pt)
+    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt)
     res["seg_fwd"] = event_time_ms(lambda: ops._seg_fwd(proj, mask, W, pt), reps, st)
     dseg = torch.randn_like(seg)
-    dproj = ops._seg_bwd(dseg, arg, proj, mask, W, pt)
-    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, arg, proj, mask, W, pt), reps, st)
+    dproj = ops._seg_bwd(dseg, arg, rec, proj.shape[1], W, pt)
+    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, arg, rec, proj.shape[1], W, pt), reps, st)
     res["smpl_bwd(skin+blend+pose)"] = event_time_ms(
         lambda: ops._smpl_bwd(x, 4, consts, Rs, J, A, v_posed, None, dproj, None), reps, st)
     return {k: round(v * 1e3, 2) for k, v in res.items()}

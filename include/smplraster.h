@@ -117,24 +117,31 @@ int smplr_visibility(const float *proj, int B, int VP, int grid_wh, int ref_comp
  *   part_pos (K) int32: positions into the VP-long vertex list, part-major (K = 6879);
  *   part_off (P+1) int32: CSR offsets of the P parts.
  * mask values must be >= 0 (the reference produces {1, 500}).
- * workspace: smplr_seg_workspace(B,VP,W,P,K) bytes of scratch the call fills (per-mesh lists of
- *   far-reaching vertices, part-major, and of nearest-pixel-only vertices, pixel-major).
+ * workspace: smplr_seg_workspace(B,VP,W,P,K) bytes of scratch.
  * seg (B,W,W,P+1): channel 0 = 1 - clip(sum_p score_p, 0, 1); channel 1+p =
  *   max_v exp(-mask_v * |proj_v - (c,r)|); rows flipped (:68).  Scores below the fp32
  *   underflow threshold (mask*d >= 104) are exactly 0, as they are in fp32 arithmetic.
- * arg (B,W,W,32) int16, slot = channel: slot 0 = 1 iff 0 <= sum_p <= 1 (the clip's pass-through
- *   gate), slot 1+p = position (in the VP list) of the maximising vertex of part p, or -1 when
- *   no vertex contributes a non-zero score.  Requires P <= 31, VP <= 32767, W <= 160.          */
+ * rec (B,S,4) fp32, S = smplr_seg_slots(P,K): the mesh's compact record list
+ *   (u, v, mask^2, vertex position as int32 bits) - first the far-reaching (visible) vertices,
+ *   part-major, then the nearest-pixel-only ones; the last slot's first word holds the number
+ *   of used slots.  Only the used prefix (and that header) is written.
+ * arg (B,W,W,32) int16, slot = channel: [0] = 1 iff 0 <= sum_p <= 1 (the clip's pass-through
+ *   gate); [1+p] = index into rec[b] of the maximising vertex of part p, or -1 when no vertex
+ *   contributes a non-zero score.  rec + arg are what the backward needs (no proj/mask/seg).
+ * Requires P <= 31, VP <= 32767, W <= 160.                                                     */
+int smplr_seg_slots(int P, int K);
 size_t smplr_seg_workspace(int B, int VP, int W, int P, int K);
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W,
                   const int32_t *part_pos, const int32_t *part_off, int P, int K,
-                  void *workspace, float *seg, int16_t *arg, void *stream);
+                  void *workspace, float *seg, int16_t *arg, float *rec, void *stream);
 
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:
- * NaN).  The score is recomputed from the arg-min vertex, so seg itself is not an input.      */
-int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *proj, const float *mask,
-                  int B, int VP, int W, int P, float *dproj, void *stream);
+ * NaN).  The score is recomputed from the arg-min record, so seg itself is not an input.
+ * workspace: smplr_seg_bwd_workspace(B,W) bytes (per-row-block partial sums, merged in order). */
+size_t smplr_seg_bwd_workspace(int B, int W);
+int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
+                  int B, int VP, int W, int P, int K, float *dproj, void *workspace, void *stream);
 
 /* ---- projects_to_silhouette: keras_smpl/projects_to_silhouette.py:14-44 ----------------- */
 /* silh (B,W,W,2) = [1-s, s], s = max_v exp(-|proj_v-(c,r)|/1.2) over ALL VP vertices, rows

@@ -62,15 +62,40 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-#pragma unroll 5
-  for (int k0 = 0; k0 < KP; k0 += 2) {
-    const float a = sA[(k0 + h) * A_LD + i];
-    const float *brow = blend + (size_t)(k0 + h) * N3;
+  // B operand double-buffered in registers: batch q+1 (11 k-steps = 33 loads) is in flight while
+  // the 33 MFMAs of batch q run, so one wave per SIMD is enough to cover the L2/HBM latency.
+  constexpr int NB = 11;                       // k-steps per batch; 10 batches x 22 rows = 220
+  float b0[NB][3], b1[NB][3];
+  auto load_batch = [&](float (&b)[NB][3], int kb) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const float b = brow[col[t]];
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    for (int s2 = 0; s2 < NB; ++s2) {
+      const float *brow = blend + (size_t)(kb + 2 * s2 + h) * N3;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) b[s2][t] = brow[col[t]];
     }
+  };
+  auto mma_batch = [&](const float (&b)[NB][3], int kb) {
+#pragma unroll
+    for (int s2 = 0; s2 < NB; ++s2) {
+      const float a = sA[(kb + 2 * s2 + h) * A_LD + i];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[s2][t], acc[t], 0, 0, 0);
+    }
+  };
+  // sched_barrier pins "issue the next batch's loads, then run this batch's MFMAs": left alone the
+  // scheduler sinks the loads next to their uses (8 in flight) and the loop stalls on L2 latency.
+  load_batch(b0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < 10; q += 2) {
+    load_batch(b1, (q + 1) * 2 * NB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_batch(b0, q * 2 * NB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (q + 2 < 10) load_batch(b0, (q + 2) * 2 * NB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_batch(b1, (q + 1) * 2 * NB);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
 #pragma unroll
@@ -101,9 +126,14 @@ constexpr int BW_LD = 33;
 
 __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dvp,
                                                         const float *__restrict__ blendT, int B, int N3,
-                                                        int cols_per_block, float *__restrict__ part) {
+                                                        int cols_per_block, int nslices, int nmt,
+                                                        float *__restrict__ part) {
   __shared__ float smem[32 * BW_NO];          // 28,672 B: 4 wave tiles (4 x 32 x 33) then the reduction buffer
-  const int slice = blockIdx.x, mt = blockIdx.y;
+  // XCD-aware map (as the forward): the nmt mesh tiles of one column slice share an XCD's L2.
+  const int bid = blockIdx.x;
+  const int group = bid / (8 * nmt), within = bid % (8 * nmt);
+  const int slice = group * 8 + (within & 7), mt = within >> 3;
+  if (slice >= nslices) return;
   const int m0 = mt * 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
@@ -128,18 +158,43 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int s = 0; s < BW_ST / 2; ++s) {
-      const int kk = 2 * s + h;
-      const float a = sAw[kk * BW_LD + i];
-      int cr = c0 + kk;
-      cr = cr < N3 ? cr : N3 - 1;              // a == 0 there
-      const float *brow = blendT + (size_t)cr * BW_NO + i;
+    // 16 k-steps in 4 batches of 4; batch q+1's 28 B loads fly under batch q's 28 MFMAs
+    constexpr int NBB = 4;
+    float b0[NBB][BW_NT], b1[NBB][BW_NT];
+    auto load_b = [&](float (&b)[NBB][BW_NT], int s0) {
 #pragma unroll
-      for (int t = 0; t < BW_NT; ++t) {
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[t * 32], acc[t], 0, 0, 0);
+      for (int s2 = 0; s2 < NBB; ++s2) {
+        int cr = c0 + 2 * (s0 + s2) + h;
+        cr = cr < N3 ? cr : N3 - 1;            // a == 0 there
+        const float *brow = blendT + (size_t)cr * BW_NO + i;
+#pragma unroll
+        for (int t = 0; t < BW_NT; ++t) b[s2][t] = brow[t * 32];
       }
-    }
+    };
+    auto mma_b = [&](const float (&b)[NBB][BW_NT], int s0) {
+#pragma unroll
+      for (int s2 = 0; s2 < NBB; ++s2) {
+        const float a = sAw[(2 * (s0 + s2) + h) * BW_LD + i];
+#pragma unroll
+        for (int t = 0; t < BW_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[s2][t], acc[t], 0, 0, 0);
+      }
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(b0, 0);
+    load_b(b1, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_b(b0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(b0, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_b(b1, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(b1, 12);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_b(b0, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_b(b1, 12);
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
   }
@@ -159,7 +214,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
     }
   }
   __syncthreads();
-  float *dst = part + ((size_t)slice * gridDim.y + mt) * (32 * BW_NO);
+  float *dst = part + ((size_t)slice * nmt + mt) * (32 * BW_NO);
   for (int e = tid; e < 32 * BW_NO; e += 256) dst[e] = sR[e];
 }
 
@@ -223,8 +278,9 @@ int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3, 
   const int nmt = (B + 31) / 32;
   int ns, cpb;
   bwd_geometry(B, N3, &ns, &cpb);
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(ns, nmt), dim3(256), 0, as_stream(stream), dv_posed, blend_t, B, N3,
-                     cpb, reinterpret_cast<float *>(workspace));
+  const int grid = ((ns + 7) / 8) * 8 * nmt;
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dv_posed, blend_t, B, N3,
+                     cpb, ns, nmt, reinterpret_cast<float *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_blend_bwd");
   hipLaunchKernelGGL(blend_bwd_reduce_kernel, dim3((B * KP + 255) / 256), dim3(256), 0,
                      as_stream(stream), reinterpret_cast<const float *>(workspace), B, ns, nmt, dcoef);

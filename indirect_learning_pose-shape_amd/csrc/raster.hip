@@ -30,6 +30,7 @@
 namespace smplr {
 
 constexpr int CH = SMPLR_CHUNK;      // 8: silhouette list padding
+static int set_lds_attr(const void *fn, size_t lds);
 constexpr int RT = 256;              // pixels (threads) per raster block
 constexpr float X_ZERO = 104.0f;     // expf(-x) rounds to 0 in fp32 for x >= 104
 constexpr float M_LOCAL = 208.0f;    // m > 208 => 104/m < 0.5 px: only the nearest pixel centre
@@ -89,12 +90,14 @@ __device__ __forceinline__ Slot classify(const float *__restrict__ pj, const flo
   return s;
 }
 
-// workspace per mesh: G[Kpad] float4 | goff[P+1] | lstart[npix+1] | lrec[K] uint2
+// rec[n] (S = Kpad + K slots of (u, v, m^2, vertex)): [0, goff[P]) the global list, part-major,
+// padded per part; [goff[P], goff[P] + L) the local records in pixel order.  Saved for backward.
+// scratch per mesh: goff[P+1] | lstart[npix+1] | lrec[K] uint2 (x bits, part)
 __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict__ proj,
                                                         const float *__restrict__ mask,
                                                         const int *__restrict__ part_pos,
                                                         const int *__restrict__ part_off, int P, int K,
-                                                        int VP, int W, int Kpad, float4 *__restrict__ G,
+                                                        int VP, int W, int S, float4 *__restrict__ G,
                                                         int *__restrict__ goff, int *__restrict__ lstart,
                                                         uint2 *__restrict__ lrec) {
   extern __shared__ int s_cnt[];   // npix
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   const int npix = W * W;
   const float *pj = proj + (size_t)n * VP * 3;
   const float *mk = mask + (size_t)n * VP;
-  float4 *Gn = G + (size_t)n * Kpad;
+  float4 *Gn = G + (size_t)n * S;
   int *goffn = goff + (size_t)n * (P + 1);
   int *lstartn = lstart + (size_t)n * (npix + 1);
   uint2 *lrecn = lrec + (size_t)n * K;
@@ -190,10 +193,12 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
         ++run;
       } else if (s.cls == 2) {
         const int dst = atomicAdd(&s_cnt[s.pix], 1);
-        lrecn[dst] = make_uint2(__float_as_uint(s.x), ((unsigned)s.pos << 8) | (unsigned)p);
+        lrecn[dst] = make_uint2(__float_as_uint(s.x), (unsigned)p);
+        Gn[s_gpad[P] + dst] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
       }
     }
   }
+  if (tid == 0) Gn[S - 1] = make_float4(__int_as_float(s_gpad[P] + lstartn[npix]), 0.f, 0.f, __int_as_float(-1));
   // sentinels in the padding
   if (tid < P) {
     const int cnt = s_gstart[tid + 1] - s_gstart[tid];
@@ -207,73 +212,124 @@ __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
   return fmaf(du, du, dv * dv) * a.z;
 }
 
+// exp(-x) for x >= 0 on the transcendental unit (v_exp_f32; rel. error ~ 1e-7 * (1 + x))
+__device__ __forceinline__ float fast_exp_neg(float x) { return __expf(-x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 constexpr int HC = 16;    // channels per half
 constexpr int TLD = 17;   // tile row stride
+
+// One vertex against this lane's pixel: strict '<' keeps the first arg-min in list order.
+#define SMPLR_PAIR(rec, slot)                                   \
+  {                                                             \
+    const float key_ = pair_key(rec, fc, fr);                   \
+    const bool lt_ = key_ < best;                               \
+    best = lt_ ? key_ : best;                                   \
+    bslot = lt_ ? (slot) : bslot;                               \
+  }
+
+// Launder a wave-uniform index so the optimiser cannot fold a prefetch back into its use.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// Scalar (wave-uniform) record loads issued from inline asm so that they can be double-buffered:
+// SMEM returns out of order, so hipcc makes every use of a scalar load wait lgkmcnt(0), which
+// also drains a prefetch issued in between.  Here a group of 4 records (64 B) is fetched with one
+// s_load_dwordx16 while the previous group is evaluated, and the wait is placed by hand right
+// before the new group's first use.  The compiler never touches a group between its load and
+// its wait (the "+s" on the wait statement is the group's only way to its uses).
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload_group(f32x16s &dst, const float4 *p) {
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(dst) : "s"(p) : "memory");
+  __builtin_amdgcn_sched_barrier(0);   // keep the other group's VALU work BELOW the prefetch
+}
+__device__ __forceinline__ void swait_group(f32x16s &v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+}
+#define SMPLR_GROUP(grp, k)                                                        \
+  SMPLR_PAIR(make_float4(grp[0], grp[1], grp[2], grp[3]), (k))                     \
+  SMPLR_PAIR(make_float4(grp[4], grp[5], grp[6], grp[7]), (k) + 1)                 \
+  SMPLR_PAIR(make_float4(grp[8], grp[9], grp[10], grp[11]), (k) + 2)               \
+  SMPLR_PAIR(make_float4(grp[12], grp[13], grp[14], grp[15]), (k) + 3)
 
 __global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict__ G,
                                                         const int *__restrict__ goff,
                                                         const int *__restrict__ lstart,
                                                         const uint2 *__restrict__ lrec, int P, int K,
-                                                        int Kpad, int W, float *__restrict__ seg,
-                                                        short *__restrict__ arg) {
+                                                        int S, int W, int B, int ntiles,
+                                                        float *__restrict__ seg, short *__restrict__ arg) {
   __shared__ float sS[RT * TLD];
   __shared__ short sA[RT * TLD];
-  const int n = blockIdx.y;
+  // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
+  // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int n = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
+  if (n >= B) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int npix = W * W;
-  const int q = blockIdx.x * RT + tid;
-  const bool live = q < npix;
-  const int qc = live ? q : npix - 1;
+  const int q = tile * RT + tid;
+  const int qc = q < npix ? q : npix - 1;
   const int r = qc / W, c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
-  const float4 *Gn = G + (size_t)n * Kpad;
+  const float4 *Gn = G + (size_t)n * S;
   const int *goffn = goff + (size_t)n * (P + 1);
   const int C = P + 1;
   const int l0 = lstart[(size_t)n * (npix + 1) + qc], l1 = lstart[(size_t)n * (npix + 1) + qc + 1];
   const uint2 *lrecn = lrec + (size_t)n * K;
+  const int lbase = goffn[P];
   float *myS = &sS[tid * TLD];
   short *myA = &sA[tid * TLD];
 
   float sum = 0.0f;
   for (int half = 1; half >= 0; --half) {
     const int ch0 = half * HC;
+    const int p_first = (ch0 == 0) ? 0 : ch0 - 1;
+    int beg = goffn[p_first < P ? p_first : P];
+    int nxt = goffn[(p_first + 1) < P ? (p_first + 1) : P];     // end of the current part
     for (int j = 0; j < HC; ++j) {
       const int ch = ch0 + j;
       if (ch == 0 || ch >= C) { myS[j] = 0.0f; myA[j] = -1; continue; }
       const int p = ch - 1;
-      const int beg = goffn[p], end = goffn[p + 1];      // wave-uniform
+      const int end = nxt;
+      nxt = goffn[opaque((p + 2) < P ? (p + 2) : P)];           // prefetch the next part's end
       float best = INFINITY;
-      int bestk = beg;
-      for (int k = beg; k < end; k += GP) {
-        const float k0 = pair_key(Gn[k], fc, fr), k1 = pair_key(Gn[k + 1], fc, fr);
-        const float k2 = pair_key(Gn[k + 2], fc, fr), k3 = pair_key(Gn[k + 3], fc, fr);
-        const float cm = fminf(fminf(k0, k1), fminf(k2, k3));
-        if (cm < best) { best = cm; bestk = k; }
-      }
-      float score = 0.0f;
-      int pos = -1;
-      if (best < INFINITY) {
-#pragma unroll
-        for (int jj = GP - 1; jj >= 0; --jj) {
-          const float4 a = Gn[bestk + jj];
-          if (pair_key(a, fc, fr) == best) pos = __float_as_int(a.w);
+      int bslot = -1;
+      if (beg < end) {
+        // two record groups in flight: group k+4 is being fetched while group k is evaluated
+        f32x16s ga, gb;
+        sload_group(ga, Gn + beg);
+        swait_group(ga);
+        int k = beg;
+        while (true) {
+          sload_group(gb, Gn + ((k + GP < end) ? k + GP : k));
+          SMPLR_GROUP(ga, k)
+          swait_group(gb);
+          k += GP;
+          if (k >= end) break;
+          sload_group(ga, Gn + ((k + GP < end) ? k + GP : k));
+          SMPLR_GROUP(gb, k)
+          swait_group(ga);
+          k += GP;
+          if (k >= end) break;
         }
-        score = expf(-sqrtf(best));
       }
-      myS[j] = score;
-      myA[j] = (short)pos;
+      myS[j] = (best < INFINITY) ? fast_exp_neg(fast_sqrt(best)) : 0.0f;
+      myA[j] = (short)bslot;
+      beg = end;
     }
     // merge this pixel's local records (invisible vertices that round to this pixel)
     for (int i = l0; i < l1; ++i) {
       const uint2 rec = lrecn[i];
-      const int ch = 1 + (int)(rec.y & 0xFFu);
+      const int ch = 1 + (int)rec.y;
       if (ch >= ch0 && ch < ch0 + HC) {
-        const float sc = expf(-__uint_as_float(rec.x));
-        const int j = ch - ch0, pos = (int)(rec.y >> 8);
-        const float cur = myS[j];
-        if (sc > cur || (sc == cur && sc > 0.0f && (myA[j] < 0 || pos < (int)myA[j]))) {
+        const float sc = fast_exp_neg(__uint_as_float(rec.x));
+        const int j = ch - ch0;
+        if (sc > myS[j]) {                                   // ties keep the earlier (global) winner
           myS[j] = sc;
-          myA[j] = (short)pos;
+          myA[j] = (short)(lbase + i);
         }
       }
     }
@@ -285,7 +341,7 @@ __global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict
     __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): tile writes done
     __builtin_amdgcn_wave_barrier();
     // write this half: 64 pixels x 16 channels; lane -> (pixel, 4-channel group)
-    const int q0 = blockIdx.x * RT + wave * 64;
+    const int q0 = tile * RT + wave * 64;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int e = it * 64 + lane;
@@ -303,9 +359,9 @@ __global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict
           for (int t = 0; t < 4; ++t)
             if (ch0 + c4 + t < C) so[t] = ts[t];
         }
-        short4 av;
-        av.x = ta[0]; av.y = ta[1]; av.z = ta[2]; av.w = ta[3];
-        *reinterpret_cast<short4 *>(arg + o * 32 + ch0 + c4) = av;
+        short4 o4;
+        o4.x = ta[0]; o4.y = ta[1]; o4.z = ta[2]; o4.w = ta[3];
+        *reinterpret_cast<short4 *>(arg + o * 32 + ch0 + c4) = o4;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -314,49 +370,128 @@ __global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// dproj (B,VP,3) must be zero on entry (the launcher memsets it).  grid (nsplit, B).
-__global__ __launch_bounds__(1024) void seg_bwd_kernel(const float *__restrict__ dseg,
-                                                       const short *__restrict__ arg,
-                                                       const float *__restrict__ proj,
-                                                       const float *__restrict__ mask, int VP, int W, int P,
-                                                       float *__restrict__ dproj) {
-  extern __shared__ float acc[];   // VP*2
-  const int n = blockIdx.y, tid = threadIdx.x;
-  for (int i = tid; i < VP * 2; i += 1024) acc[i] = 0.0f;
-  __syncthreads();
-  const int C = P + 1, npix = W * W;
-  const float *pj = proj + (size_t)n * VP * 3;
-  const float *mk = mask + (size_t)n * VP;
-  const int per = (npix + gridDim.x - 1) / gridDim.x;
-  const int o_beg = blockIdx.x * per, o_end = min(npix, o_beg + per);
-  for (int e = o_beg * 32 + tid; e < o_end * 32; e += 1024) {
-    const int o = e >> 5, ch = e & 31;       // o = output pixel index (flipped row-major)
-    const size_t po = (size_t)n * npix + o;
-    const int a = arg[po * 32 + ch];
-    const float gv = (ch < C) ? dseg[po * C + ch] : 0.0f;
-    const int gate = __shfl(a, 0, 32);       // channel-0 lane of this pixel
-    const float g0 = __shfl(gv, 0, 32);
-    if (ch >= 1 && ch < C && a >= 0) {
-      const float g = gv - (gate ? g0 : 0.0f);
-      const int ro = o / W, cc = o - ro * W;
-      const float fr = (float)(W - 1 - ro), fc = (float)cc;
-      const float du = pj[a * 3] - fc, dv = pj[a * 3 + 1] - fr;
-      const float m = mk[a];
-      const float d = sqrtf(fmaf(du, du, dv * dv));
-      const float sc = expf(-(d * m));
-      const float k = -g * sc * m;
-      if (d > 0.0f && k != 0.0f) {
-        const float kk = k / d;
-        atomicAdd(&acc[a * 2], kk * du);
-        atomicAdd(&acc[a * 2 + 1], kk * dv);
-      }
+// Segmentation backward.  grid (ceil(W/8), B), 256 threads = 8 strips x 32 channels: a 32-lane
+// group walks one output row at a time, lane = channel, so dseg/arg are read as whole 128-B /
+// 64-B pixel rows (coalesced) and neighbouring lanes hit different parts.  Along a row the
+// arg-min of a part changes rarely, so each lane sums the run of pixels that share a slot in
+// registers and only touches the LDS accumulator (ds_add_f32 runs at ~1 lane/clk) at run
+// boundaries.  The arg-min record comes from the mesh's compact list (a few KB: L1-resident) as
+// one 16-B gather; the score is recomputed from it (seg is not re-read).
+// Per-block slot sums go to a partial buffer with plain coalesced stores and are summed in fixed
+// order by seg_bwd_merge_kernel, which scatters each slot to its vertex (one slot per vertex, so
+// plain stores).  Slots >= SB_SLOTS (only meshes with > 4096 records) use global atomics.
+constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators
+constexpr int SB_ROWS = 8;       // rows (strips) per block
+constexpr int SB_U = 4;          // pixels in flight per lane
+
+__device__ __forceinline__ void seg_flush(float *acc, const float4 *R, float *dp, int cur, float sx, float sy) {
+  if (cur >= 0 && (sx != 0.0f || sy != 0.0f)) {
+    if (cur < SB_SLOTS) {
+      atomicAdd(&acc[cur * 2], sx);
+      atomicAdd(&acc[cur * 2 + 1], sy);
+    } else {
+      const int v = __float_as_int(R[cur].w);
+      atomicAdd(&dp[v * 3], sx);
+      atomicAdd(&dp[v * 3 + 1], sy);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ dseg,
+                                                      const short *__restrict__ arg,
+                                                      const float4 *__restrict__ rec, int S, int VP, int W,
+                                                      int P, float *__restrict__ dproj,
+                                                      float *__restrict__ part) {
+  __shared__ float acc[SB_SLOTS * 2];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const float4 *R = rec + (size_t)n * S;
+  const int nslots = __float_as_int(R[S - 1].x);
+  const int nsl = nslots < SB_SLOTS ? nslots : SB_SLOTS;
+  for (int i = tid; i < nsl * 2; i += 256) acc[i] = 0.0f;
   __syncthreads();
-  float *o = dproj + (size_t)n * VP * 3;
-  for (int i = tid; i < VP * 2; i += 1024) {
-    const float v = acc[i];
-    if (v != 0.0f) atomicAdd(&o[(i >> 1) * 3 + (i & 1)], v);
+  const int C = P + 1, npix = W * W;
+  float *dp = dproj + (size_t)n * VP * 3;
+  const int ch = tid & 31, strip = tid >> 5;
+  const int ro = blockIdx.x * SB_ROWS + strip;            // output (flipped) row of this strip
+  if (ro < W) {
+    const float fr = (float)(W - 1 - ro);
+    const size_t row0 = (size_t)n * npix + (size_t)ro * W;
+    int cur = -1;
+    float sx = 0.0f, sy = 0.0f;
+    for (int c0 = 0; c0 < W; c0 += SB_U) {
+      int a[SB_U];
+      float g[SB_U];
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) {
+        const int cc = (c0 + u < W) ? c0 + u : W - 1;
+        const size_t po = row0 + cc;
+        a[u] = arg[po * 32 + ch];
+        g[u] = (ch < C) ? dseg[po * C + ch] : 0.0f;
+      }
+      float4 rv[SB_U];
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) {
+        const int gate = __shfl(a[u], 0, 32);     // channel-0 lane of this pixel: 1 = clip passes gradient
+        const float g0 = __shfl(g[u], 0, 32);
+        g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
+        if (!(ch >= 1 && ch < C && c0 + u < W)) a[u] = -1;
+        rv[u] = R[a[u] >= 0 ? a[u] : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) {
+        if (a[u] >= 0) {
+          const float fc = (float)(c0 + u);
+          const float du = rv[u].x - fc, dv = rv[u].y - fr;
+          const float d2 = fmaf(du, du, dv * dv);
+          const float x = fast_sqrt(d2 * rv[u].z);          // m * d, as the forward computed it
+          // d score / d(u,v) = -score * m * (p - q) / d = -score * x * (p - q) / d^2
+          const float k = -g[u] * fast_exp_neg(x) * x;
+          if (d2 > 0.0f && k != 0.0f) {
+            const float kk = k / d2;
+            if (a[u] != cur) {
+              seg_flush(acc, R, dp, cur, sx, sy);
+              cur = a[u];
+              sx = 0.0f;
+              sy = 0.0f;
+            }
+            sx = fmaf(kk, du, sx);
+            sy = fmaf(kk, dv, sy);
+          }
+        }
+      }
+    }
+    seg_flush(acc, R, dp, cur, sx, sy);
+  }
+  __syncthreads();
+  float *dst = part + ((size_t)n * gridDim.x + blockIdx.x) * (SB_SLOTS * 2);
+  for (int i = tid; i < nsl * 2; i += 256) dst[i] = acc[i];
+}
+
+__global__ __launch_bounds__(256) void seg_bwd_merge_kernel(const float *__restrict__ part,
+                                                            const float4 *__restrict__ rec, int S, int VP,
+                                                            int nsplit, float *__restrict__ dproj) {
+  const int n = blockIdx.y;
+  const float4 *R = rec + (size_t)n * S;
+  const int nslots = __float_as_int(R[S - 1].x);
+  const int nsl = nslots < SB_SLOTS ? nslots : SB_SLOTS;
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= nsl) return;
+  const int v = __float_as_int(R[slot].w);
+  if (v < 0) return;                                       // padding sentinel
+  const float *p = part + (size_t)n * nsplit * (SB_SLOTS * 2) + slot * 2;
+  float sx = 0.0f, sy = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float2 t = *reinterpret_cast<const float2 *>(p + (size_t)s * (SB_SLOTS * 2));
+    sx += t.x;
+    sy += t.y;
+  }
+  float *o = dproj + ((size_t)n * VP + v) * 3;
+  if (nslots > SB_SLOTS) {        // the overflow path may have hit this vertex' row with atomics
+    atomicAdd(&o[0], sx);
+    atomicAdd(&o[1], sy);
+  } else {
+    o[0] = sx;
+    o[1] = sy;
   }
 }
 
@@ -458,17 +593,16 @@ static int set_lds_attr(const void *fn, size_t lds) {
 }
 
 struct SegWs {
-  size_t g_off, goff_off, lstart_off, lrec_off, total;
-  int Kpad;
+  size_t goff_off, lstart_off, lrec_off, total;
 };
+
+// global list (padded per part) + local records + one spare group whose last slot is the header
+static int seg_slots(int P, int K) { return ((K + (GP - 1) * P + 3) / 4 * 4) + (K + 3) / 4 * 4 + GP; }
 
 static SegWs seg_ws_layout(int B, int W, int P, int K) {
   SegWs w;
-  w.Kpad = K + (GP - 1) * P;
-  w.Kpad = (w.Kpad + 3) / 4 * 4;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  w.g_off = take((size_t)B * w.Kpad * sizeof(float4));
   w.goff_off = take((size_t)B * (P + 1) * sizeof(int));
   w.lstart_off = take((size_t)B * ((size_t)W * W + 1) * sizeof(int));
   w.lrec_off = take((size_t)B * K * sizeof(uint2));
@@ -480,6 +614,8 @@ static SegWs seg_ws_layout(int B, int W, int P, int K) {
 
 extern "C" {
 
+int smplr_seg_slots(int P, int K) { return (P > 0 && K > 0) ? smplr::seg_slots(P, K) : 0; }
+
 size_t smplr_seg_workspace(int B, int VP, int W, int P, int K) {
   if (B <= 0 || VP <= 0 || W <= 0 || P <= 0 || K <= 0) return 0;
   return smplr::seg_ws_layout(B, W, P, K).total;
@@ -487,16 +623,18 @@ size_t smplr_seg_workspace(int B, int VP, int W, int P, int K) {
 
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, const int32_t *part_pos,
                   const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,
-                  void *stream) {
+                  float *rec, void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0,
+  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= 16000,
                 "smplr_seg_fwd: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", B, VP, W, P, K);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg, "smplr_seg_fwd: null pointer");
+  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg && rec,
+                "smplr_seg_fwd: null pointer");
   hipStream_t st = as_stream(stream);
   const SegWs ws = seg_ws_layout(B, W, P, K);
+  const int S = seg_slots(P, K);
   char *base = reinterpret_cast<char *>(workspace);
-  float4 *G = reinterpret_cast<float4 *>(base + ws.g_off);
+  float4 *G = reinterpret_cast<float4 *>(rec);
   int *goff = reinterpret_cast<int *>(base + ws.goff_off);
   int *lstart = reinterpret_cast<int *>(base + ws.lstart_off);
   uint2 *lrec = reinterpret_cast<uint2 *>(base + ws.lrec_off);
@@ -504,33 +642,40 @@ int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, co
   int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel), lds);
   if (rc) return rc;
   hipLaunchKernelGGL(seg_bin_kernel, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K, VP, W,
-                     ws.Kpad, G, goff, lstart, lrec);
+                     S, G, goff, lstart, lrec);
   SMPLR_LAUNCH_CHECK("smplr_seg_fwd(bin)");
-  hipLaunchKernelGGL(raster_fwd_kernel, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st, G, goff, lstart, lrec, P,
-                     K, ws.Kpad, W, seg, reinterpret_cast<short *>(arg));
+  const int ntiles = (W * W + RT - 1) / RT;
+  const int grid = 8 * ((B + 7) / 8) * ntiles;
+  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RT), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
+                     seg, reinterpret_cast<short *>(arg));
   SMPLR_LAUNCH_CHECK("smplr_seg_fwd");
   return 0;
 }
 
-int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *proj, const float *mask, int B, int VP,
-                  int W, int P, float *dproj, void *stream) {
+size_t smplr_seg_bwd_workspace(int B, int W) {
+  if (B <= 0 || W <= 0) return 0;
+  const int nsplit = (W + smplr::SB_ROWS - 1) / smplr::SB_ROWS;
+  return (size_t)B * nsplit * smplr::SB_SLOTS * 2 * sizeof(float);
+}
+
+int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B, int VP, int W, int P, int K,
+                  float *dproj, void *workspace, void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31,
-                "smplr_seg_bwd: bad sizes B=%d VP=%d W=%d P=%d", B, VP, W, P);
+  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= 16000,
+                "smplr_seg_bwd: bad sizes B=%d VP=%d W=%d P=%d K=%d", B, VP, W, P, K);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(dseg && arg && proj && mask && dproj, "smplr_seg_bwd: null pointer");
-  const size_t lds = (size_t)VP * 2 * sizeof(float);
-  SMPLR_REQUIRE(lds <= 150 * 1024, "smplr_seg_bwd: VP=%d needs %zu B of LDS", VP, lds);
-  int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel), lds);
-  if (rc) return rc;
+  SMPLR_REQUIRE(dseg && arg && rec && dproj && workspace, "smplr_seg_bwd: null pointer");
   hipStream_t st = as_stream(stream);
   SMPLR_HIP(hipMemsetAsync(dproj, 0, (size_t)B * VP * 3 * sizeof(float), st));
-  int nsplit = (512 + B - 1) / B;          // ~2 blocks per CU chip-wide
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > 16) nsplit = 16;
-  hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(1024), lds, st, dseg, reinterpret_cast<const short *>(arg),
-                     proj, mask, VP, W, P, dproj);
+  const int nsplit = (W + SB_ROWS - 1) / SB_ROWS;
+  const int S = seg_slots(P, K);
+  hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(256), 0, st, dseg, reinterpret_cast<const short *>(arg),
+                     reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, reinterpret_cast<float *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_seg_bwd");
+  hipLaunchKernelGGL(seg_bwd_merge_kernel, dim3(SB_SLOTS / 256, B), dim3(256), 0, st,
+                     reinterpret_cast<const float *>(workspace), reinterpret_cast<const float4 *>(rec), S, VP, nsplit,
+                     dproj);
+  SMPLR_LAUNCH_CHECK("smplr_seg_bwd(merge)");
   return 0;
 }
 

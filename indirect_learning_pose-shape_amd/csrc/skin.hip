@@ -74,8 +74,10 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
   }
 }
 
-// One block = one mesh x 256 vertices.  part layout per (mesh, block): 288 dA + 4 dcam floats.
+// One block = 256 vertices x SKB_MB meshes (the 24 skinning weights of a vertex are loaded once and
+// kept in registers / LDS for all of them).  part layout per (mesh, block): 288 dA + 4 dcam floats.
 constexpr int SKB_PART = 292;
+constexpr int SKB_MB = 4;
 
 __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
@@ -85,12 +87,13 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   __shared__ float sP[SKB_T][4];    // [v_posed;1]
   __shared__ float sRed[SKB_T / 64][SKB_PART];
   __shared__ float sW[SKB_T * SKB_WLD];
-  const int n = blockIdx.y;
+  __shared__ float4 sAj[72];        // this mesh's 24 x 12 joint matrix
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int v = blockIdx.x * SKB_T + tid;
   const bool live = v < V;
   const int vc = live ? v : V - 1;
-  const float *An = A + (size_t)n * 288;
+  const bool sampled = (vs <= 1) || (v % vs == 0);
+  const int vpi = (vs <= 1) ? v : v / vs;
 
   float w[24];
   {
@@ -101,76 +104,92 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
       w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
     }
   }
-  float T[12];
-#pragma unroll
-  for (int e = 0; e < 12; ++e) T[e] = 0.0f;
-#pragma unroll
-  for (int j = 0; j < 24; ++j)
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
-  const float *vp = v_posed + ((size_t)n * V + vc) * 3;
-  const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
-
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-  float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
-  if (live) {
-    if (dverts) {
-      const float *d = dverts + ((size_t)n * V + v) * 3;
-      g0 = d[0]; g1 = d[1]; g2 = d[2];
-    }
-    if (dproj && ((vs <= 1) || (v % vs == 0))) {
-      const float *d = dproj + ((size_t)n * VP + ((vs <= 1) ? v : v / vs)) * 3;
-      const float *c = cam + (size_t)n * x_stride;
-      const float du = d[0], dv = d[1];
-      const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
-      const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
-      g0 += c[0] * du; g1 += c[1] * dv; g2 += d[2];
-      dku = X * du; dkv = Y * dv; du0 = du; dv0 = dv;
-    }
-    float *o = dv_posed + ((size_t)n * V + v) * 3;
-    o[0] = T[0] * g0 + T[4] * g1 + T[8] * g2;
-    o[1] = T[1] * g0 + T[5] * g1 + T[9] * g2;
-    o[2] = T[2] * g0 + T[6] * g1 + T[10] * g2;
-  }
 #pragma unroll
   for (int j = 0; j < 24; ++j) sW[tid * SKB_WLD + j] = w[j];
-  sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
-  sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
   __syncthreads();
 
-  // dA tile on the matrix cores: D[joint][comp] += sum_k w[vk][joint] * g[vk][comp>>2]*ph[vk][comp&3]
   const int li = lane & 15, lk = lane >> 4;
-  const int cr = li >> 2, cc = li & 3;   // component j = li = r*4+c  (valid for li < 12)
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int cr = li >> 2, cc = li & 3;   // dT component j = li = r*4+c  (valid for li < 12)
+
+  for (int mi = 0; mi < SKB_MB; ++mi) {
+    const int n = blockIdx.y * SKB_MB + mi;     // block-uniform
+    if (n >= B) break;
+    // T = sum_j w_j A_j with the mesh's joint matrix staged in LDS (broadcast ds_read_b128) and
+    // w_j taken from LDS as well: as scalar operands the 288 matrix entries need more SGPRs than
+    // exist (the compiler then spills through v_readlane or falls back to 288 vector loads).
+    if (tid < 72) sAj[tid] = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid];
+    __syncthreads();
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.0f;
 #pragma unroll 4
-  for (int s = 0; s < 16; ++s) {
-    const int k = s * 4 + lk;                 // vertex within the wave's 64
-    const int t = wave * 64 + k;              // tail vertices carry g = 0 and finite (clamped) weights
-    const float a0 = sW[t * SKB_WLD + li];
-    const float a1 = (li < 8) ? sW[t * SKB_WLD + 16 + li] : 0.0f;
-    const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
-  }
-  // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
-  if (li < 12) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j0 = lk * 4 + r;
-      sRed[wave][j0 * 12 + li] = acc0[r];
-      if (j0 < 8) sRed[wave][(16 + j0) * 12 + li] = acc1[r];
+    for (int j = 0; j < 24; ++j) {
+      const float wj = sW[tid * SKB_WLD + j];
+      const float4 r0 = sAj[j * 3], r1 = sAj[j * 3 + 1], r2 = sAj[j * 3 + 2];
+      T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
+      T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
+      T[8] = fmaf(wj, r2.x, T[8]); T[9] = fmaf(wj, r2.y, T[9]); T[10] = fmaf(wj, r2.z, T[10]); T[11] = fmaf(wj, r2.w, T[11]);
     }
-  }
-  const float r0 = wave_sum(dku), r1 = wave_sum(dkv), r2 = wave_sum(du0), r3 = wave_sum(dv0);
-  if (lane == 0) {
-    sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
-  }
-  __syncthreads();
-  for (int e = tid; e < SKB_PART; e += SKB_T) {
-    float acc = 0.f;
+    const float *vp = v_posed + ((size_t)n * V + vc) * 3;
+    const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
+    if (live) {
+      if (dverts) {
+        const float *d = dverts + ((size_t)n * V + v) * 3;
+        g0 = d[0]; g1 = d[1]; g2 = d[2];
+      }
+      if (dproj && sampled) {
+        const float *d = dproj + ((size_t)n * VP + vpi) * 3;
+        const float *c = cam + (size_t)n * x_stride;
+        const float du = d[0], dv = d[1];
+        const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
+        const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
+        g0 += c[0] * du; g1 += c[1] * dv; g2 += d[2];
+        dku = X * du; dkv = Y * dv; du0 = du; dv0 = dv;
+      }
+      float *o = dv_posed + ((size_t)n * V + v) * 3;
+      o[0] = T[0] * g0 + T[4] * g1 + T[8] * g2;
+      o[1] = T[1] * g0 + T[5] * g1 + T[9] * g2;
+      o[2] = T[2] * g0 + T[6] * g1 + T[10] * g2;
+    }
+    sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
+    sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
+    __syncthreads();
+
+    // dA tile on the matrix cores: D[joint][comp] += sum_k w[vk][joint] * g[vk][comp>>2]*ph[vk][comp&3]
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int t = wave * 64 + s * 4 + lk;     // tail vertices carry g = 0 and finite (clamped) weights
+      const float a0 = sW[t * SKB_WLD + li];
+      const float a1 = (li < 8) ? sW[t * SKB_WLD + 16 + li] : 0.0f;
+      const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+    }
+    // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
+    if (li < 12) {
 #pragma unroll
-    for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
-    part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
+      for (int r = 0; r < 4; ++r) {
+        const int j0 = lk * 4 + r;
+        sRed[wave][j0 * 12 + li] = acc0[r];
+        if (j0 < 8) sRed[wave][(16 + j0) * 12 + li] = acc1[r];
+      }
+    }
+    const float r0 = wave_sum(dku), r1 = wave_sum(dkv), r2 = wave_sum(du0), r3 = wave_sum(dv0);
+    if (lane == 0) {
+      sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
+    }
+    __syncthreads();
+    for (int e = tid; e < SKB_PART; e += SKB_T) {
+      float acc = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
+      part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
+    }
+    __syncthreads();    // sG/sP/sRed are rewritten for the next mesh
   }
 }
 
@@ -271,7 +290,7 @@ int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed
   SMPLR_REQUIRE(!dproj || (cam && x_stride >= 4), "smplr_skin_bwd: dproj given without camera rows");
   const int VP = (V + vertex_sampling - 1) / vertex_sampling;
   const int nblk = (V + SKB_T - 1) / SKB_T;
-  hipLaunchKernelGGL(skin_bwd_kernel, dim3(nblk, B), dim3(SKB_T), 0, as_stream(stream), dverts, dproj,
+  hipLaunchKernelGGL(skin_bwd_kernel, dim3(nblk, (B + SKB_MB - 1) / SKB_MB), dim3(SKB_T), 0, as_stream(stream), dverts, dproj,
                      v_posed, lbs_weights, A, cam, x_stride, B, V, vertex_sampling, VP, dv_posed,
                      reinterpret_cast<float *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_skin_bwd");

@@ -15,5 +15,5 @@ def projects_to_seg(input, img_wh, vertex_sampling=None, return_argmin=False):
         raise RuntimeError("img_wh must be positive")
     vs = 1 if vertex_sampling in (None, 1) else int(vertex_sampling)
     pt = ops.get_part_table(vs, proj.device)
-    seg, arg = ops.SegRasterFn.apply(proj, mask, int(img_wh), pt)
-    return (seg, arg) if return_argmin else seg
+    seg, arg, rec = ops.SegRasterFn.apply(proj, mask, int(img_wh), pt)
+    return (seg, ops.argmin_vertices(arg, rec)) if return_argmin else seg

@@ -189,18 +189,30 @@ def _seg_fwd(proj, mask, W, pt: PartTable):
     ws = _workspace(lib.smplr_seg_workspace(B, VP, W, pt.P, pt.K), proj)
     seg = _empty((B, W, W, pt.P + 1), proj)
     arg = _empty((B, W, W, 32), proj, torch.int16)
+    rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
     check(lib.smplr_seg_fwd(ptr(proj), ptr(mask), B, VP, W, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
-                            pt.K, ptr(ws), ptr(seg), ptr(arg), stream()), "smplr_seg_fwd")
-    return seg, arg
+                            pt.K, ptr(ws), ptr(seg), ptr(arg), ptr(rec), stream()), "smplr_seg_fwd")
+    return seg, arg, rec
 
 
-def _seg_bwd(dseg, arg, proj, mask, W, pt: PartTable):
+def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable):
     lib = _lib.load()
-    B, VP = proj.shape[0], proj.shape[1]
-    dproj = _empty((B, VP, 3), proj)
-    check(lib.smplr_seg_bwd(ptr(dseg), ptr(arg), ptr(proj), ptr(mask), B, VP, W, pt.P,
-                            ptr(dproj), stream()), "smplr_seg_bwd")
+    B = arg.shape[0]
+    dproj = _empty((B, VP, 3), dseg)
+    ws = _workspace(lib.smplr_seg_bwd_workspace(B, W), dseg)
+    check(lib.smplr_seg_bwd(ptr(dseg), ptr(arg), ptr(rec), B, VP, W, pt.P, pt.K, ptr(dproj), ptr(ws),
+                            stream()), "smplr_seg_bwd")
     return dproj
+
+
+def argmin_vertices(arg, rec):
+    """(B,W,W,31) int64 vertex positions of the maximising vertices (-1 = none) from arg/rec."""
+    slots = arg[..., 1:].to(torch.int64)
+    B = arg.shape[0]
+    pos = rec[..., 3].contiguous().view(torch.int32).to(torch.int64)       # (B,S)
+    flat = slots.reshape(B, -1)
+    got = torch.gather(pos, 1, flat.clamp(min=0))
+    return torch.where(flat >= 0, got, torch.full_like(got, -1)).reshape(slots.shape)
 
 
 def _silh_fwd(proj, W):
@@ -229,6 +241,7 @@ class BatchSMPLFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, consts: SMPLConstants, num_cam: int):
         x = require_cuda(x, "x")
+        ctx.set_materialize_grads(False)
         coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
         v_posed = _blend_fwd(coef, consts)
         verts, _ = _skin_fwd(v_posed, A, consts)
@@ -286,17 +299,20 @@ class SegRasterFn(torch.autograd.Function):
     def forward(ctx, proj, mask, img_wh: int, pt: PartTable):
         proj = require_cuda(proj, "projects_with_depth")
         mask = require_cuda(mask, "mask_vals")
-        seg, arg = _seg_fwd(proj, mask, int(img_wh), pt)
-        ctx.W, ctx.pt = int(img_wh), pt
-        ctx.save_for_backward(proj, mask, arg)
-        ctx.mark_non_differentiable(arg)
-        return seg, arg
+        ctx.set_materialize_grads(False)
+        seg, arg, rec = _seg_fwd(proj, mask, int(img_wh), pt)
+        ctx.W, ctx.pt, ctx.VP = int(img_wh), pt, proj.shape[1]
+        ctx.save_for_backward(arg, rec)
+        ctx.mark_non_differentiable(arg, rec)
+        return seg, arg, rec
 
     @staticmethod
-    def backward(ctx, dseg, _darg):
-        proj, mask, arg = ctx.saved_tensors
+    def backward(ctx, dseg, _darg, _drec):
+        arg, rec = ctx.saved_tensors
+        if dseg is None:
+            return None, None, None, None
         dseg = require_cuda(dseg, "dseg")
-        return _seg_bwd(dseg, arg, proj, mask, ctx.W, ctx.pt), None, None, None
+        return _seg_bwd(dseg, arg, rec, ctx.VP, ctx.W, ctx.pt), None, None, None
 
 
 class SilhRasterFn(torch.autograd.Function):
@@ -330,28 +346,29 @@ class DecoderFn(torch.autograd.Function):
     def forward(ctx, x, consts: SMPLConstants, num_cam, img_wh, vertex_sampling, pt: PartTable,
                 grid_wh, ref_compat, with_silh):
         x = require_cuda(x, "x")
+        ctx.set_materialize_grads(False)
         vs = int(vertex_sampling)
         W = int(img_wh)
         coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
         v_posed = _blend_fwd(coef, consts)
         verts, proj = _skin_fwd(v_posed, A, consts, cam=x, vertex_sampling=vs)
         mask = visibility(proj, grid_wh, ref_compat)
-        seg, arg = _seg_fwd(proj, mask, W, pt)
+        seg, arg, rec = _seg_fwd(proj, mask, W, pt)
         if with_silh:
             silh, sarg = _silh_fwd(proj, W)
         else:
             silh = sarg = torch.empty(0, device=x.device)
         ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, with_silh
-        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, mask, arg, silh, sarg)
+        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg)
         ctx.mark_non_differentiable(mask)
         return verts, proj, mask, seg, silh, Jt
 
     @staticmethod
     def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
-        x, Rs, J, A, v_posed, proj, mask, arg, silh, sarg = ctx.saved_tensors
+        x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg = ctx.saved_tensors
         dproj = None
         if dseg is not None:
-            dproj = _seg_bwd(require_cuda(dseg, "dseg"), arg, proj, mask, ctx.W, ctx.pt)
+            dproj = _seg_bwd(require_cuda(dseg, "dseg"), arg, rec, proj.shape[1], ctx.W, ctx.pt)
         if ctx.with_silh and dsilh is not None:
             d2 = _silh_bwd(require_cuda(dsilh, "dsilh"), silh, sarg, proj, ctx.W)
             dproj = d2 if dproj is None else dproj + d2
