@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="meshes per GPU")
     ap.add_argument("--wh", type=int, default=48)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent mesh chunks per step (HIP streams / parallel graph branches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
@@ -162,7 +164,8 @@ def main():
 
     def step():
         xg = x.detach().requires_grad_(True)
-        verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False)
+        verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False,
+                                                               args.streams)
         seg.backward(dseg)
         return xg.grad
 
@@ -220,7 +223,8 @@ def main():
             "config": {"workload": "full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
                                    "projects_to_seg), BASELINE configs[2]",
                        "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,
-                       "params_per_mesh": 86, "launch": mode, "sharding": "by mesh, no collective"},
+                       "params_per_mesh": 86, "launch": mode, "concurrent_chunks": args.streams,
+                       "sharding": "by mesh, no collective"},
         }
         if not args.no_breakdown:
             stages = stage_breakdown(x, consts, pt, W)

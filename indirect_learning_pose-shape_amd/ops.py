@@ -108,42 +108,45 @@ def _workspace(nbytes, like):
 
 
 # --------------------------------------------------------------------------- raw stage calls
-def _pose_fwd(x, num_cam, c: SMPLConstants):
+def _pose_fwd(x, num_cam, c: SMPLConstants, out=None):
     lib = _lib.load()
     B = x.shape[0]
-    coef = _empty((B, KPAD), x)
-    Rs = _empty((B, 24, 9), x)
-    J = _empty((B, 24, 3), x)
-    A = _empty((B, 24, 12), x)
-    Jt = _empty((B, 24, 3), x)
+    if out is None:
+        out = (_empty((B, KPAD), x), _empty((B, 24, 9), x), _empty((B, 24, 3), x), _empty((B, 24, 12), x),
+               _empty((B, 24, 3), x))
+    coef, Rs, J, A, Jt = out
     check(lib.smplr_pose_fwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_template), ptr(c.J_dirs),
                              ptr(c.parents), ptr(coef), ptr(Rs), ptr(J), ptr(A), ptr(Jt), stream()),
           "smplr_pose_fwd")
     return coef, Rs, J, A, Jt
 
 
-def _blend_fwd(coef, c: SMPLConstants):
+def _blend_fwd(coef, c: SMPLConstants, out=None):
     lib = _lib.load()
     B = coef.shape[0]
-    v_posed = _empty((B, c.V, 3), coef)
+    v_posed = _empty((B, c.V, 3), coef) if out is None else out
     check(lib.smplr_blend_fwd(ptr(coef), ptr(c.blend), ptr(c.v_template), B, 3 * c.V, ptr(v_posed),
                               stream()), "smplr_blend_fwd")
     return v_posed
 
 
-def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_verts=True):
+def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_verts=True, out=None):
     lib = _lib.load()
     B = v_posed.shape[0]
     vs = int(vertex_sampling)
-    verts = _empty((B, c.V, 3), v_posed) if want_verts else None
-    proj = _empty((B, (c.V + vs - 1) // vs, 3), v_posed) if cam is not None else None
+    if out is not None:
+        verts, proj = out
+    else:
+        verts = _empty((B, c.V, 3), v_posed) if want_verts else None
+        proj = _empty((B, (c.V + vs - 1) // vs, 3), v_posed) if cam is not None else None
     check(lib.smplr_skin_fwd(ptr(v_posed), ptr(c.lbs_weights), ptr(A), ptr(cam),
                              cam.shape[1] if cam is not None else 0, B, c.V, vs, ptr(verts), ptr(proj),
                              stream()), "smplr_skin_fwd")
     return verts, proj
 
 
-def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJt, vertex_sampling=1):
+def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJt, vertex_sampling=1,
+              out=None):
     """dverts and/or dproj (+ optional dJ_transformed) -> dx (B, x_stride)."""
     lib = _lib.load()
     B = x.shape[0]
@@ -159,7 +162,7 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
     ws2 = _workspace(lib.smplr_blend_bwd_workspace(B, 3 * c.V), x)
     check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend_t), B, 3 * c.V, ptr(dcoef), ptr(ws2), stream()),
           "smplr_blend_bwd")
-    dx = _empty(tuple(x.shape), x)
+    dx = _empty(tuple(x.shape), x) if out is None else out
     if x.shape[1] > num_cam + 82:
         dx.zero_()
     check(lib.smplr_pose_bwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_dirs), ptr(c.parents), ptr(Rs),
@@ -168,28 +171,31 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
     return dx
 
 
-def visibility(proj, grid_wh=64, ref_compat=True):
+def visibility(proj, grid_wh=64, ref_compat=True, out=None):
     """compute_mask (keras_smpl/compute_mask.py:12-108), stateless; no gradient (:30)."""
     lib = _lib.load()
     proj = require_cuda(proj.detach(), "projects_with_depth")
     if proj.dim() != 3 or proj.shape[2] != 3:
         raise RuntimeError("projects_with_depth must be (B, V', 3)")
     B, VP = proj.shape[0], proj.shape[1]
-    mask = _empty((B, VP), proj)
+    mask = _empty((B, VP), proj) if out is None else out
     check(lib.smplr_visibility(ptr(proj), B, VP, int(grid_wh), 1 if ref_compat else 0, ptr(mask),
                                stream()), "smplr_visibility")
     return mask
 
 
-def _seg_fwd(proj, mask, W, pt: PartTable):
+def _seg_fwd(proj, mask, W, pt: PartTable, out=None):
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
     if VP != pt.VP:
         raise RuntimeError("projects has %d vertices but the part table expects %d" % (VP, pt.VP))
     ws = _workspace(lib.smplr_seg_workspace(B, VP, W, pt.P, pt.K), proj)
-    seg = _empty((B, W, W, pt.P + 1), proj)
-    arg = _empty((B, W, W, 32), proj, torch.int16)
-    rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
+    if out is not None:
+        seg, arg, rec = out
+    else:
+        seg = _empty((B, W, W, pt.P + 1), proj)
+        arg = _empty((B, W, W, 32), proj, torch.int16)
+        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
     check(lib.smplr_seg_fwd(ptr(proj), ptr(mask), B, VP, W, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
                             pt.K, ptr(ws), ptr(seg), ptr(arg), ptr(rec), stream()), "smplr_seg_fwd")
     return seg, arg, rec
@@ -215,11 +221,14 @@ def argmin_vertices(arg, rec):
     return torch.where(flat >= 0, got, torch.full_like(got, -1)).reshape(slots.shape)
 
 
-def _silh_fwd(proj, W):
+def _silh_fwd(proj, W, out=None):
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
-    silh = _empty((B, W, W, 2), proj)
-    arg = _empty((B, W, W), proj, torch.int32)
+    if out is not None:
+        silh, arg = out
+    else:
+        silh = _empty((B, W, W, 2), proj)
+        arg = _empty((B, W, W), proj, torch.int32)
     ws = _workspace(lib.smplr_silh_workspace(B, VP), proj)
     check(lib.smplr_silh_fwd(ptr(proj), B, VP, W, ptr(silh), ptr(arg), ptr(ws), stream()), "smplr_silh_fwd")
     return silh, arg
@@ -334,31 +343,93 @@ class SilhRasterFn(torch.autograd.Function):
         return _silh_bwd(dsilh, silh, arg, proj, ctx.W), None
 
 
+_side_streams = {}
+
+
+def _chunk_streams(device, k):
+    """k side streams per device, created once (HIP streams are cheap to keep)."""
+    key = str(device)
+    pool = _side_streams.setdefault(key, [])
+    while len(pool) < k:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:k]
+
+
+def _chunk_bounds(B, nchunk):
+    nchunk = max(1, min(int(nchunk), B)) if B > 0 else 1
+    base, rem = divmod(B, nchunk)
+    out, lo = [], 0
+    for i in range(nchunk):
+        hi = lo + base + (1 if i < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _run_chunks(bounds, device, fn):
+    """fn(lo, hi) for every chunk: one chunk inline, several on side streams that fork from and
+    join back into the current stream (parallel branches when captured into a HIP graph)."""
+    if len(bounds) == 1:
+        fn(*bounds[0])
+        return
+    cur = torch.cuda.current_stream()
+    streams = _chunk_streams(device, len(bounds))
+    for st, (lo, hi) in zip(streams, bounds):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            fn(lo, hi)
+    for st in streams:
+        cur.wait_stream(st)
+
+
 class DecoderFn(torch.autograd.Function):
     """The model.py:108-118 chain as ONE autograd node.
 
     x (B, 86) -> verts (B,V,3), proj (B,V',3), mask (B,V'), seg (B,W,W,32) [, silh (B,W,W,2)].
     The projection is the skinning kernel's epilogue, the mask is computed in between, and the
     backward fuses d(seg)/d(silh)/d(verts)/d(proj) into one skinning-backward launch.
+
+    Every op is independent per mesh, so the batch may be cut into `nchunk` contiguous chunks
+    whose kernel sequences run concurrently on separate HIP streams: at B = 128 most kernels are
+    latency-bound (a fraction of a wave per SIMD), and concurrent chunks fill the idle SIMDs.
+    Results are identical for any nchunk.
     """
 
     @staticmethod
     def forward(ctx, x, consts: SMPLConstants, num_cam, img_wh, vertex_sampling, pt: PartTable,
-                grid_wh, ref_compat, with_silh):
+                grid_wh, ref_compat, with_silh, nchunk=1):
         x = require_cuda(x, "x")
         ctx.set_materialize_grads(False)
-        vs = int(vertex_sampling)
-        W = int(img_wh)
-        coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
-        v_posed = _blend_fwd(coef, consts)
-        verts, proj = _skin_fwd(v_posed, A, consts, cam=x, vertex_sampling=vs)
-        mask = visibility(proj, grid_wh, ref_compat)
-        seg, arg, rec = _seg_fwd(proj, mask, W, pt)
+        lib = _lib.load()
+        vs, W, B = int(vertex_sampling), int(img_wh), x.shape[0]
+        V, VP = consts.V, (consts.V + vs - 1) // vs
+        coef, Rs, J = _empty((B, KPAD), x), _empty((B, 24, 9), x), _empty((B, 24, 3), x)
+        A, Jt = _empty((B, 24, 12), x), _empty((B, 24, 3), x)
+        v_posed, verts, proj = _empty((B, V, 3), x), _empty((B, V, 3), x), _empty((B, VP, 3), x)
+        mask = _empty((B, VP), x)
+        seg, arg = _empty((B, W, W, pt.P + 1), x), _empty((B, W, W, 32), x, torch.int16)
+        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), x)
         if with_silh:
-            silh, sarg = _silh_fwd(proj, W)
+            silh, sarg = _empty((B, W, W, 2), x), _empty((B, W, W), x, torch.int32)
         else:
             silh = sarg = torch.empty(0, device=x.device)
+
+        def run(lo, hi):
+            xs = x[lo:hi]
+            _pose_fwd(xs, num_cam, consts, out=(coef[lo:hi], Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))
+            _blend_fwd(coef[lo:hi], consts, out=v_posed[lo:hi])
+            _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
+                      out=(verts[lo:hi], proj[lo:hi]))
+            visibility(proj[lo:hi], grid_wh, ref_compat, out=mask[lo:hi])
+            _seg_fwd(proj[lo:hi], mask[lo:hi], W, pt, out=(seg[lo:hi], arg[lo:hi], rec[lo:hi]))
+            if with_silh:
+                _silh_fwd(proj[lo:hi], W, out=(silh[lo:hi], sarg[lo:hi]))
+
+        bounds = _chunk_bounds(B, nchunk)
+        if B > 0:
+            _run_chunks(bounds, x.device, run)
         ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, with_silh
+        ctx.bounds = bounds
         ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg)
         ctx.mark_non_differentiable(mask)
         return verts, proj, mask, seg, silh, Jt
@@ -366,18 +437,29 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
         x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg = ctx.saved_tensors
-        dproj = None
-        if dseg is not None:
-            dproj = _seg_bwd(require_cuda(dseg, "dseg"), arg, rec, proj.shape[1], ctx.W, ctx.pt)
-        if ctx.with_silh and dsilh is not None:
-            d2 = _silh_bwd(require_cuda(dsilh, "dsilh"), silh, sarg, proj, ctx.W)
-            dproj = d2 if dproj is None else dproj + d2
-        if dproj_in is not None:
-            dproj_in = require_cuda(dproj_in, "dproj")
-            dproj = dproj_in if dproj is None else dproj + dproj_in
+        dseg = require_cuda(dseg, "dseg") if dseg is not None else None
+        dsilh = require_cuda(dsilh, "dsilh") if (ctx.with_silh and dsilh is not None) else None
+        dproj_in = require_cuda(dproj_in, "dproj") if dproj_in is not None else None
         dverts = require_cuda(dverts, "dverts") if dverts is not None else None
         dJt = require_cuda(dJt, "dJ_transformed") if dJt is not None else None
-        if dverts is None and dproj is None:
-            dverts = torch.zeros_like(v_posed)
-        dx = _smpl_bwd(x, ctx.num_cam, ctx.consts, Rs, J, A, v_posed, dverts, dproj, dJt, ctx.vs)
-        return (dx,) + (None,) * 8
+        VP = proj.shape[1]
+        dx = _empty(tuple(x.shape), x)
+
+        def run(lo, hi):
+            dproj = None
+            if dseg is not None:
+                dproj = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt)
+            if dsilh is not None:
+                d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.W)
+                dproj = d2 if dproj is None else dproj + d2
+            if dproj_in is not None:
+                dproj = dproj_in[lo:hi] if dproj is None else dproj + dproj_in[lo:hi]
+            dv = dverts[lo:hi] if dverts is not None else None
+            if dv is None and dproj is None:
+                dv = torch.zeros_like(v_posed[lo:hi])
+            _smpl_bwd(x[lo:hi], ctx.num_cam, ctx.consts, Rs[lo:hi], J[lo:hi], A[lo:hi], v_posed[lo:hi], dv,
+                      dproj, dJt[lo:hi] if dJt is not None else None, ctx.vs, out=dx[lo:hi])
+
+        if x.shape[0] > 0:
+            _run_chunks(ctx.bounds, x.device, run)
+        return (dx,) + (None,) * 9

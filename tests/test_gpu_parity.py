@@ -314,3 +314,22 @@ def test_native_library_loaded():
     _lib.load()
     maps = open("/proc/self/maps").read()
     assert "libsmplraster_hip.so" in maps
+
+
+def test_concurrent_chunks_identical(smpl_model):
+    """Cutting the batch into chunks that run on separate HIP streams must not change any value."""
+    from ilps_amd.decoder import SMPLDecoder
+    W, B = 48, 11
+    x = make_x(B, W, seed=71)
+    g = np.random.default_rng(3).normal(0, 1, (B, W, W, 32))
+    outs = []
+    for k in (1, 4):
+        dec = SMPLDecoder(smpl_model, img_wh=W, streams=k)
+        xg = t(x).requires_grad_(True)
+        o = dec(xg)
+        (o["seg"] * t(g)).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((o["verts"].detach().clone(), o["seg"].detach().clone(), o["mask"].clone(), xg.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    grad_close(outs[1][3].cpu().numpy(), outs[0][3].cpu().numpy(), 1e-5, "dx chunks vs whole")
