@@ -6,12 +6,11 @@
 // Reference: keras_smpl/batch_smpl.py:106-108 (shape blend, K.dot) and :126-128 (pose blend,
 // K.dot) fused into one contraction over [beta | pose_feature].
 //
-// Forward tiling: workgroup = 4 waves = 32 meshes x 384 columns, each wave a 32x96 strip
-// (3 accumulator tiles).  coef^T sits in LDS ([k][mesh], row stride 33 -> conflict-free both
-// ways); the B operand needs no transpose so each wave reads blend rows straight from
-// global/L2 (two 128-B row segments per load).  The blockIdx -> (column block, mesh tile)
-// map keeps the mesh tiles that share a column block on one XCD (blocks b and b+8 share an
-// L2), so blend is fetched from HBM/MALL once and re-read from L2.
+// Forward tiling: workgroup = 4 waves = 128 meshes x one 96-column strip, each wave a 32x96 tile
+// (3 accumulator tiles) of a different mesh tile.  coef^T of all 128 meshes sits in LDS
+// ([tile][k][mesh], row stride 33 -> conflict-free both ways); the B operand needs no transpose
+// so each wave reads blend rows straight from global in MFMA layout (two 128-B row segments
+// per load) and the four waves share those lines through L1.
 //
 // Backward tiling: workgroup = 32 meshes x all 220 outputs (7 tiles) x one slice of columns,
 // against the TRANSPOSED constant blendT (N3 x 224) so that no operand of the big matrix needs a
@@ -24,32 +23,47 @@ namespace smplr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KP = SMPLR_KPAD;  // 220
-constexpr int FW_BM = 32, FW_WN = 96, FW_BN = 384;
+constexpr int FW_BM = 32, FW_WN = 96;
 constexpr int A_LD = 33;
 
+// grid (column strips of 96, groups of 128 meshes); the 4 waves of a block are the 4 mesh tiles of
+// ONE strip, so they issue identical B-operand loads and the CU's L1 serves three of them: the
+// big matrix crosses L2->L1 once per 128 meshes instead of once per 32.
 __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict__ coef,
                                                         const float *__restrict__ blend,
                                                         const float *__restrict__ vt, int B, int N3,
-                                                        int ncb, int nmt, float *__restrict__ out) {
-  __shared__ float sA[KP * A_LD];
-  // XCD-aware map: within a group of 8*nmt consecutive blocks, the nmt blocks with equal
-  // (bid % 8) take the same column block.
-  const int bid = blockIdx.x;
-  const int group = bid / (8 * nmt), within = bid % (8 * nmt);
-  const int cb = group * 8 + (within & 7), mt = within >> 3;
-  if (cb >= ncb) return;
-  const int m0 = mt * FW_BM;
+                                                        float *__restrict__ out) {
+  extern __shared__ float sAall[];          // 4 x [220][33]: coef^T of the 4 mesh tiles
+  const int strip = blockIdx.x, mg = blockIdx.y;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-
-  for (int e = tid; e < FW_BM * KP; e += 256) {
-    const int i = e / KP, k = e % KP;
-    const int m = m0 + i;
-    sA[k * A_LD + i] = (m < B) ? coef[(size_t)m * KP + k] : 0.0f;
+  const int mbase = mg * 4 * FW_BM;
+  {
+    const int rows = min(4 * FW_BM, B - mbase);          // meshes present in this group
+    const float *src = coef + (size_t)mbase * KP;        // contiguous rows*220 floats
+    // 28,160 contiguous floats, 110 per thread: 11 loads in flight, then their 11 LDS stores
+    const int nvalid = rows * KP;
+    for (int e0 = tid; e0 < 4 * FW_BM * KP; e0 += 256 * 11) {
+      float v[11];
+#pragma unroll
+      for (int u = 0; u < 11; ++u) {
+        const int e = e0 + u * 256;
+        v[u] = (e < nvalid) ? src[e] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 11; ++u) {
+        const int e = e0 + u * 256;
+        const int i = e / KP, k = e - i * KP;
+        sAall[(i >> 5) * (KP * A_LD) + k * A_LD + (i & 31)] = v[u];
+      }
+    }
   }
   __syncthreads();
+  const int m0 = mbase + wave * FW_BM;
+  if (m0 >= B) return;                                   // this wave's mesh tile is empty
+  const float *sA = sAall + wave * (KP * A_LD);
 
   const int i = lane & 31, h = lane >> 5;
-  const int cw = cb * FW_BN + wave * FW_WN;
+  const int cw = strip * FW_WN;
   int col[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
@@ -75,11 +89,13 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
     }
   };
   auto mma_batch = [&](const float (&b)[NB][3], int kb) {
+    float a[NB];                                // the batch's A operands first: no LDS wait per k-step
+#pragma unroll
+    for (int s2 = 0; s2 < NB; ++s2) a[s2] = sA[(kb + 2 * s2 + h) * A_LD + i];
 #pragma unroll
     for (int s2 = 0; s2 < NB; ++s2) {
-      const float a = sA[(kb + 2 * s2 + h) * A_LD + i];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[s2][t], acc[t], 0, 0, 0);
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2][t], acc[t], 0, 0, 0);
     }
   };
   // sched_barrier pins "issue the next batch's loads, then run this batch's MFMAs": left alone the
@@ -150,11 +166,16 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
   for (int c0 = c_beg; c0 < c_end; c0 += BW_ST) {
     if (c0 >= N3) break;                       // wave-uniform
     // stage A: 32 meshes x 32 columns, coalesced along c, stored [c][mesh]
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 2 + h, col = i;
-      const int m = m0 + row, cc = c0 + col;
-      sAw[col * BW_LD + row] = (m < B && cc < N3) ? dvp[(size_t)m * N3 + cc] : 0.0f;
+    {
+      float v[16];
+      const int cc = c0 + i;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int m = m0 + it * 2 + h;
+        v[it] = (m < B && cc < N3) ? dvp[(size_t)m * N3 + cc] : 0.0f;
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) sAw[i * BW_LD + it * 2 + h] = v[it];
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -172,11 +193,13 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
       }
     };
     auto mma_b = [&](const float (&b)[NBB][BW_NT], int s0) {
+      float a[NBB];
+#pragma unroll
+      for (int s2 = 0; s2 < NBB; ++s2) a[s2] = sAw[(2 * (s0 + s2) + h) * BW_LD + i];
 #pragma unroll
       for (int s2 = 0; s2 < NBB; ++s2) {
-        const float a = sAw[(2 * (s0 + s2) + h) * BW_LD + i];
 #pragma unroll
-        for (int t = 0; t < BW_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[s2][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < BW_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2][t], acc[t], 0, 0, 0);
       }
     };
     __builtin_amdgcn_sched_barrier(0);
@@ -253,10 +276,16 @@ int smplr_blend_fwd(const float *coef, const float *blend, const float *v_templa
   SMPLR_REQUIRE(B >= 0 && N3 > 0, "smplr_blend_fwd: bad sizes B=%d N3=%d", B, N3);
   if (B == 0) return 0;
   SMPLR_REQUIRE(coef && blend && v_template && v_posed, "smplr_blend_fwd: null pointer");
-  const int ncb = (N3 + FW_BN - 1) / FW_BN, nmt = (B + FW_BM - 1) / FW_BM;
-  const int grid = ((ncb + 7) / 8) * 8 * nmt;
-  hipLaunchKernelGGL(blend_fwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), coef, blend,
-                     v_template, B, N3, ncb, nmt, v_posed);
+  const int nstrips = (N3 + FW_WN - 1) / FW_WN, ngroups = (B + 4 * FW_BM - 1) / (4 * FW_BM);
+  const size_t lds = (size_t)4 * KP * A_LD * sizeof(float);     // 116,160 B
+  static bool attr_set = false;
+  if (!attr_set) {
+    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blend_fwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(blend_fwd_kernel, dim3(nstrips, ngroups), dim3(256), lds, as_stream(stream), coef, blend,
+                     v_template, B, N3, v_posed);
   SMPLR_LAUNCH_CHECK("smplr_blend_fwd");
   return 0;
 }
