@@ -36,6 +36,7 @@ constexpr float X_ZERO = 104.0f;     // expf(-x) rounds to 0 in fp32 for x >= 10
 constexpr float M_LOCAL = 208.0f;    // m > 208 => 104/m < 0.5 px: only the nearest pixel centre
 constexpr int GP = 4;                // global-list group size (padding granule)
 constexpr int BIN_T = 1024;
+constexpr int IPT_MAX = 8;           // part-table slots per bin thread: K <= 8192
 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int block_excl_scan(int val, int *s_wave /*[BIN_T/64]*/, int *total) {
@@ -114,14 +115,19 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   if (tid <= P) s_poff[tid] = part_off[tid];
   for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
   __syncthreads();
-  const int ipt = (K + BIN_T - 1) / BIN_T;
+  const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
   const int k0 = tid * ipt, k1 = min(K, k0 + ipt);
-  // pass 1: counts
+  // pass 1: classify each of this thread's slots ONCE (three dependent gathers per slot: keep the
+  // results in registers for the later passes), count
+  Slot sl[IPT_MAX];
   int gcnt = 0;
-  for (int k = k0; k < k1; ++k) {
-    const Slot s = classify(pj, mk, part_pos[k], W);
-    if (s.cls == 1) ++gcnt;
-    else if (s.cls == 2) atomicAdd(&s_cnt[s.pix], 1);
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int k = k0 + j;
+    sl[j].cls = 0;
+    if (j < ipt && k < k1) sl[j] = classify(pj, mk, part_pos[k], W);
+    if (sl[j].cls == 1) ++gcnt;
+    else if (sl[j].cls == 2) atomicAdd(&s_cnt[sl[j].pix], 1);
   }
   int gtotal;
   const int gbase = block_excl_scan(gcnt, s_wave, &gtotal);
@@ -154,11 +160,14 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       p = lo;
     }
     int run = gbase;
-    for (int k = k0; k < k1; ++k) {
-      while (k >= s_poff[p + 1]) ++p;
-      for (int pp = p; pp >= 0 && s_poff[pp] == k; --pp) s_gstart[pp] = run;   // (also empty parts)
-      const Slot s = classify(pj, mk, part_pos[k], W);
-      if (s.cls == 1) ++run;
+#pragma unroll
+    for (int j = 0; j < IPT_MAX; ++j) {
+      const int k = k0 + j;
+      if (j < ipt && k < k1) {
+        while (k >= s_poff[p + 1]) ++p;
+        for (int pp = p; pp >= 0 && s_poff[pp] == k; --pp) s_gstart[pp] = run;   // (also empty parts)
+        if (sl[j].cls == 1) ++run;
+      }
     }
   }
   __syncthreads();
@@ -185,9 +194,12 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       p = lo;
     }
     int run = gbase;
-    for (int k = k0; k < k1; ++k) {
+#pragma unroll
+    for (int j = 0; j < IPT_MAX; ++j) {
+      const int k = k0 + j;
+      if (!(j < ipt && k < k1)) continue;
       while (k >= s_poff[p + 1]) ++p;
-      const Slot s = classify(pj, mk, part_pos[k], W);
+      const Slot s = sl[j];
       if (s.cls == 1) {
         Gn[s_gpad[p] + (run - s_gstart[p])] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
         ++run;
@@ -625,7 +637,7 @@ int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, co
                   const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,
                   float *rec, void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= 16000,
+  SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
                 "smplr_seg_fwd: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", B, VP, W, P, K);
   if (B == 0) return 0;
   SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg && rec,
