@@ -120,7 +120,16 @@ def cpu_baseline(model, W, budget_s=20.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 2000:
             break
+    cpu_model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(Bc * n / el, 3), "unit": "meshes/s", "cores": int(torch.get_num_threads()),
+            "cpu": cpu_model, "os_cpu_count": os.cpu_count(),
             "kind": "port",
             "sample": "%d fwd+bwd passes of the full decoder at B=%d, W=%d (%.1f s); fp32 torch-CPU "
                       "restatement of the reference's dense formulation (TensorFlow itself is not "
@@ -256,6 +265,20 @@ def main():
                         "whose fp32 score is provably 0 are never evaluated: executed_* counts only evaluated pairs",
                 "launch_us": stages["seg_fwd"],
             }
+        if not args.no_breakdown:
+            # BASELINE configs[1]: batch_smpl fwd+bwd only, B=256, eager, HIP events
+            x2 = torch.tensor(make_x(256, W, 7), device=dev)
+            gv = torch.randn(256, consts.V, 3, device=dev)
+
+            def smpl_only():
+                xg = x2.detach().requires_grad_(True)
+                v, _jt = ops.BatchSMPLFn.apply(xg, consts, 4)
+                v.backward(gv)
+            for _ in range(5):
+                smpl_only()
+            t_smpl = event_time_ms(smpl_only, 30, torch.cuda.current_stream())
+            line["aux"] = {"batch_smpl_fwd_bwd_B256": {"meshes_per_s": round(256 / (t_smpl * 1e-3), 1),
+                                                       "ms_per_step": round(t_smpl, 4), "launch": "eager"}}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(model, W)

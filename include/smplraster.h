@@ -97,6 +97,17 @@ int smplr_skin_bwd(const float *dverts, const float *dproj,
                    const float *cam, int x_stride, int B, int V, int vertex_sampling,
                    float *dv_posed, float *dA, float *dcam, void *workspace, void *stream);
 
+/* Fused backward of the whole SMPLLayer (+ projection epilogue): smplr_skin_bwd -> smplr_blend_bwd ->
+ * smplr_pose_bwd in three launches, the partial sums of the first two folded into the third
+ * (fixed summation order).  Same semantics as chaining the three entry points above.
+ * workspace: smplr_smpl_bwd_workspace(B,V) bytes.                                              */
+size_t smplr_smpl_bwd_workspace(int B, int V);
+int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed,
+                   const float *x, int x_stride, int num_cam, int B, int V, int vertex_sampling,
+                   const float *blend_t, const float *lbs_weights, const float *J_dirs,
+                   const int32_t *parents, const float *Rs, const float *J, const float *A,
+                   const float *v_posed, float *dx, void *workspace, void *stream);
+
 /* ---- orthographic_project: keras_smpl/projection.py:54-81 ------------------------------ */
 int smplr_project_fwd(const float *verts, const float *cam, int x_stride, int B, int V,
                       int vertex_sampling, float *proj, void *stream);

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
 #pragma unroll
       for (int u = 0; u < 11; ++u) {
         const int e = e0 + u * 256;
-        v[u] = (e < nvalid) ? src[e] : 0.0f;
+        const float ld = src[min(e, nvalid - 1)];       // unconditional (clamped) load, select afterwards
+        v[u] = (e < nvalid) ? ld : 0.0f;
       }
 #pragma unroll
       for (int u = 0; u < 11; ++u) {
@@ -266,6 +267,24 @@ static void bwd_geometry(int B, int N3, int *nslices, int *cols_per_block) {
   *nslices = (N3 + cpb - 1) / cpb;
 }
 
+BlendBwdGeom blend_bwd_geom(int B, int N3) {
+  BlendBwdGeom g;
+  g.nmt = (B + 31) / 32;
+  bwd_geometry(B, N3, &g.nslices, &g.cols_per_block);
+  g.part_floats = (size_t)g.nslices * g.nmt * 32 * BW_NO;
+  return g;
+}
+
+int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B, int N3, float *part,
+                              hipStream_t st) {
+  const BlendBwdGeom g = blend_bwd_geom(B, N3);
+  const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, st, dv_posed, blend_t, B, N3, g.cols_per_block,
+                     g.nslices, g.nmt, part);
+  SMPLR_LAUNCH_CHECK("blend_bwd_kernel");
+  return 0;
+}
+
 }  // namespace smplr
 
 extern "C" {
@@ -304,13 +323,11 @@ int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3, 
   SMPLR_REQUIRE(B >= 0 && N3 > 0, "smplr_blend_bwd: bad sizes B=%d N3=%d", B, N3);
   if (B == 0) return 0;
   SMPLR_REQUIRE(dv_posed && blend_t && dcoef && workspace, "smplr_blend_bwd: null pointer");
-  const int nmt = (B + 31) / 32;
-  int ns, cpb;
-  bwd_geometry(B, N3, &ns, &cpb);
-  const int grid = ((ns + 7) / 8) * 8 * nmt;
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, as_stream(stream), dv_posed, blend_t, B, N3,
-                     cpb, ns, nmt, reinterpret_cast<float *>(workspace));
-  SMPLR_LAUNCH_CHECK("smplr_blend_bwd");
+  const BlendBwdGeom g = blend_bwd_geom(B, N3);
+  const int ns = g.nslices, nmt = g.nmt;
+  int rc = launch_blend_bwd_partials(dv_posed, blend_t, B, N3, reinterpret_cast<float *>(workspace),
+                                     as_stream(stream));
+  if (rc) return rc;
   hipLaunchKernelGGL(blend_bwd_reduce_kernel, dim3((B * KP + 255) / 256), dim3(256), 0,
                      as_stream(stream), reinterpret_cast<const float *>(workspace), B, ns, nmt, dcoef);
   SMPLR_LAUNCH_CHECK("smplr_blend_bwd(reduce)");

@@ -40,6 +40,17 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int WAVE = 64;
 
+// Internal pieces of the fused SMPL backward (smplr_smpl_bwd, pose.hip): the partial-sum producers
+// without their stand-alone reduction kernels.
+struct BlendBwdGeom { int nslices, cols_per_block, nmt; size_t part_floats; };
+BlendBwdGeom blend_bwd_geom(int B, int N3);
+int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B, int N3, float *part,
+                              hipStream_t st);
+int skin_bwd_nblk(int V);
+int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
+                             const float *lbs_weights, const float *A, const float *cam, int x_stride, int B,
+                             int V, int vs, float *dv_posed, float *part, hipStream_t st);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -36,6 +36,9 @@ struct PoseLds {
   float dGt[24][3];
   float dJ[24][3];
   float dR[24][9];
+  float dA[24][12];     // backward inputs, summed from the producers' partials when fused
+  float dcoef[220];
+  float dcam[4];
 };
 
 // R = cos*I + (1-cos)*r r^T + sin*skew(r),  angle = |theta + 1e-8|, r = theta/angle.
@@ -177,8 +180,15 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     const float *__restrict__ J_dirs, const int *__restrict__ parents,
     const float *__restrict__ Rs_in, const float *__restrict__ J_in, const float *__restrict__ A_in,
     const float *__restrict__ dcoef, const float *__restrict__ dA, const float *__restrict__ dnewJ,
-    const float *__restrict__ dcam, float *__restrict__ dx) {
+    const float *__restrict__ dcam, float *__restrict__ dx,
+    // fused mode (dA == nullptr): sum the skinning partials (B,nblk,292) and the split-K partials
+    // (ns,nmt,32,224) of the blend GEMM here, in fixed order, instead of in two more launches
+    const float *__restrict__ skin_part, int nblk, const float *__restrict__ blend_part, int ns, int nmt,
+    int want_dcam) {
   __shared__ PoseLds lds[MPB];
+  __shared__ float sJd[720];           // J_dirs, shared by the block's meshes (the d beta loop walks all of it)
+  for (int e = threadIdx.x; e < 720; e += MPB * 64) sJd[e] = J_dirs[e];
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.x * MPB + wave;
   const bool live = n < B;
@@ -189,11 +199,55 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     for (int e = lane; e < 216; e += 64) L.Rs[e / 9][e % 9] = Rs_in[nn * 216 + e];
     for (int e = lane; e < 72; e += 64) L.J[e / 3][e % 3] = J_in[nn * 72 + e];
     for (int e = lane; e < 288; e += 64) L.G[e / 12][e % 12] = A_in[nn * 288 + e];  // G.R = A.R
+    if (dA) {
+      for (int e = lane; e < 288; e += 64) L.dA[e / 12][e % 12] = dA[nn * 288 + e];
+      for (int e = lane; e < 220; e += 64) L.dcoef[e] = dcoef[nn * SMPLR_KPAD + e];
+      if (lane < 4) L.dcam[lane] = dcam ? dcam[nn * 4 + lane] : 0.0f;
+    } else {
+      // all of a lane's entries accumulate side by side so that one memory round trip serves
+      // 5 (4) x 9 loads instead of 9: the partials were written by the previous kernels and come
+      // from L2/HBM at ~1 us per dependent trip
+      {
+        const float *p = skin_part + (nn * nblk) * 292;
+        int off[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) off[j] = min(lane + 64 * j, 291);   // clamped: loads stay unconditional
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 9
+        for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+          for (int j = 0; j < 5; ++j) acc[j] += p[(size_t)b * 292 + off[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int e = lane + 64 * j;
+          if (e < 288) L.dA[e / 12][e % 12] = acc[j];
+          else if (e < 292) L.dcam[e - 288] = want_dcam ? acc[j] : 0.0f;
+        }
+      }
+      {
+        const size_t mt = nn >> 5, r = nn & 31;
+        const float *p = blend_part + (mt * 32 + r) * 224;
+        const size_t stride = (size_t)nmt * 32 * 224;
+        int off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) off[j] = min(lane + 64 * j, 223);   // row stride is 224: always valid
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 9
+        for (int s = 0; s < ns; ++s) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += p[s * stride + off[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (lane + 64 * j < 220) L.dcoef[lane + 64 * j] = acc[j];
+      }
+    }
   }
   wave_sync();
   if (live && lane < 24) {
     const int i = lane;
-    const float *dAi = dA + nn * 288 + i * 12;
+    const float *dAi = &L.dA[i][0];
     float dAt[3] = {dAi[3], dAi[7], dAi[11]};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -234,7 +288,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
   if (live) {
     float *dxr = dx + nn * x_stride;
     const float *xr = x + nn * x_stride;
-    const float *dc = dcoef + nn * SMPLR_KPAD;
+    const float *dc = L.dcoef;
     if (lane < 24) {
       float g[9];
 #pragma unroll
@@ -247,11 +301,12 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     } else if (lane >= 32 && lane < 42) {
       const int k = lane - 32;
       float acc = dc[k];
-      for (int e = 0; e < 72; ++e) acc += L.dJ[e / 3][e % 3] * J_dirs[e * 10 + k];
+#pragma unroll 8
+      for (int e = 0; e < 72; ++e) acc += L.dJ[e / 3][e % 3] * sJd[e * 10 + k];
       dxr[num_cam + 72 + k] = acc;
     } else if (lane >= 48 && lane < 48 + num_cam) {
       const int cidx = lane - 48;
-      dxr[cidx] = (dcam && cidx < 4) ? dcam[nn * 4 + cidx] : 0.0f;
+      dxr[cidx] = (cidx < 4) ? L.dcam[cidx] : 0.0f;
     }
   }
 }
@@ -288,8 +343,53 @@ int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B, const float
   if (B == 0) return 0;
   SMPLR_REQUIRE(x && J_dirs && parents && Rs && J && A && dcoef && dA && dx, "smplr_pose_bwd: null pointer");
   hipLaunchKernelGGL(pose_bwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
-                     x, x_stride, num_cam, B, J_dirs, parents, Rs, J, A, dcoef, dA, dJ_transformed, dcam, dx);
+                     x, x_stride, num_cam, B, J_dirs, parents, Rs, J, A, dcoef, dA, dJ_transformed, dcam, dx,
+                     (const float *)nullptr, 0, (const float *)nullptr, 0, 0, 0);
   SMPLR_LAUNCH_CHECK("smplr_pose_bwd");
+  return 0;
+}
+
+static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+size_t smplr_smpl_bwd_workspace(int B, int V) {
+  using namespace smplr;
+  if (B <= 0 || V <= 0) return 0;
+  return align256((size_t)B * V * 3 * sizeof(float)) + align256((size_t)B * skin_bwd_nblk(V) * 292 * sizeof(float)) +
+         align256(blend_bwd_geom(B, 3 * V).part_floats * sizeof(float));
+}
+
+int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed, const float *x,
+                   int x_stride, int num_cam, int B, int V, int vertex_sampling, const float *blend_t,
+                   const float *lbs_weights, const float *J_dirs, const int32_t *parents, const float *Rs,
+                   const float *J, const float *A, const float *v_posed, float *dx, void *workspace,
+                   void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && V > 0 && num_cam >= 0 && num_cam <= 16 && x_stride >= num_cam + 82 &&
+                    vertex_sampling >= 1 && vertex_sampling <= V,
+                "smplr_smpl_bwd: bad sizes B=%d V=%d num_cam=%d x_stride=%d vs=%d", B, V, num_cam, x_stride,
+                vertex_sampling);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(x && blend_t && lbs_weights && J_dirs && parents && Rs && J && A && v_posed && dx && workspace,
+                "smplr_smpl_bwd: null pointer");
+  SMPLR_REQUIRE(dverts || dproj, "smplr_smpl_bwd: need dverts and/or dproj");
+  SMPLR_REQUIRE(!dproj || (num_cam >= 4), "smplr_smpl_bwd: dproj needs the 4 camera columns");
+  hipStream_t st = as_stream(stream);
+  char *base = reinterpret_cast<char *>(workspace);
+  float *dv_posed = reinterpret_cast<float *>(base);
+  float *skin_part = reinterpret_cast<float *>(base + align256((size_t)B * V * 3 * sizeof(float)));
+  float *blend_part = reinterpret_cast<float *>(reinterpret_cast<char *>(skin_part) +
+                                                align256((size_t)B * skin_bwd_nblk(V) * 292 * sizeof(float)));
+  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, A, dproj ? x : nullptr, x_stride, B, V,
+                                    vertex_sampling, dv_posed, skin_part, st);
+  if (rc) return rc;
+  rc = launch_blend_bwd_partials(dv_posed, blend_t, B, 3 * V, blend_part, st);
+  if (rc) return rc;
+  const BlendBwdGeom g = blend_bwd_geom(B, 3 * V);
+  hipLaunchKernelGGL(pose_bwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, st, x, x_stride, num_cam, B,
+                     J_dirs, parents, Rs, J, A, (const float *)nullptr, (const float *)nullptr, dJ_transformed,
+                     (const float *)nullptr, dx, skin_part, skin_bwd_nblk(V), blend_part, g.nslices, g.nmt,
+                     dproj ? 1 : 0);
+  SMPLR_LAUNCH_CHECK("smplr_smpl_bwd(pose)");
   return 0;
 }
 

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
         const int cc = (c0 + u < W) ? c0 + u : W - 1;
         const size_t po = row0 + cc;
         a[u] = arg[po * 32 + ch];
-        g[u] = (ch < C) ? dseg[po * C + ch] : 0.0f;
+        g[u] = dseg[po * C + min(ch, C - 1)];       // unconditional load (slots >= C are masked below)
       }
       float4 rv[SB_U];
 #pragma unroll

@@ -248,6 +248,18 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restric
   if (tid < 4) dcam[(size_t)n * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+int skin_bwd_nblk(int V) { return (V + SKB_T - 1) / SKB_T; }
+
+int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
+                             const float *lbs_weights, const float *A, const float *cam, int x_stride, int B,
+                             int V, int vs, float *dv_posed, float *part, hipStream_t st) {
+  const int VP = (V + vs - 1) / vs;
+  hipLaunchKernelGGL(skin_bwd_kernel, dim3(skin_bwd_nblk(V), (B + SKB_MB - 1) / SKB_MB), dim3(SKB_T), 0, st, dverts,
+                     dproj, v_posed, lbs_weights, A, cam, x_stride, B, V, vs, VP, dv_posed, part);
+  SMPLR_LAUNCH_CHECK("skin_bwd_kernel");
+  return 0;
+}
+
 }  // namespace smplr
 
 extern "C" {
@@ -288,12 +300,10 @@ int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed
   SMPLR_REQUIRE(v_posed && lbs_weights && A && dv_posed && dA && workspace, "smplr_skin_bwd: null pointer");
   SMPLR_REQUIRE(dverts || dproj, "smplr_skin_bwd: need dverts and/or dproj");
   SMPLR_REQUIRE(!dproj || (cam && x_stride >= 4), "smplr_skin_bwd: dproj given without camera rows");
-  const int VP = (V + vertex_sampling - 1) / vertex_sampling;
-  const int nblk = (V + SKB_T - 1) / SKB_T;
-  hipLaunchKernelGGL(skin_bwd_kernel, dim3(nblk, (B + SKB_MB - 1) / SKB_MB), dim3(SKB_T), 0, as_stream(stream), dverts, dproj,
-                     v_posed, lbs_weights, A, cam, x_stride, B, V, vertex_sampling, VP, dv_posed,
-                     reinterpret_cast<float *>(workspace));
-  SMPLR_LAUNCH_CHECK("smplr_skin_bwd");
+  const int nblk = skin_bwd_nblk(V);
+  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, A, cam, x_stride, B, V, vertex_sampling,
+                                    dv_posed, reinterpret_cast<float *>(workspace), as_stream(stream));
+  if (rc) return rc;
   hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(B), dim3(320), 0, as_stream(stream),
                      reinterpret_cast<const float *>(workspace), nblk, dA, dcam);
   SMPLR_LAUNCH_CHECK("smplr_skin_bwd(reduce)");

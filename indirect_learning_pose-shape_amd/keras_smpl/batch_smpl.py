@@ -66,6 +66,14 @@ class SMPLLayer(nn.Module):
         self.J_transformed = jt
         return verts
 
+    def joints(self, verts):
+        """cocoplus (19) / lsp (14) joints from posed vertices: the output the reference leaves
+        commented out at batch_smpl.py:147-151.  A plain library GEMM (rocBLAS), (B,V,3) -> (B,Jn,3)."""
+        jr = self.constants(verts.device).joint_regressor
+        if jr is None:
+            raise RuntimeError("this SMPL model has no cocoplus_regressor")
+        return torch.einsum("bvc,vj->bjc", verts, jr)
+
     def compute_output_shape(self, input_shape):        # batch_smpl.py:155-159
         return (input_shape[0], self.size[0], self.size[1])
 

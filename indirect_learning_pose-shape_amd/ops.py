@@ -151,23 +151,13 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
     lib = _lib.load()
     B = x.shape[0]
     vs = int(vertex_sampling)
-    dv_posed = _empty((B, c.V, 3), x)
-    dA = _empty((B, 24, 12), x)
-    dcam = _empty((B, 4), x) if dproj is not None else None
-    ws = _workspace(lib.smplr_skin_bwd_workspace(B, c.V), x)
-    check(lib.smplr_skin_bwd(ptr(dverts), ptr(dproj), ptr(v_posed), ptr(c.lbs_weights), ptr(A),
-                             ptr(x) if dproj is not None else None, x.shape[1], B, c.V, vs,
-                             ptr(dv_posed), ptr(dA), ptr(dcam), ptr(ws), stream()), "smplr_skin_bwd")
-    dcoef = _empty((B, KPAD), x)
-    ws2 = _workspace(lib.smplr_blend_bwd_workspace(B, 3 * c.V), x)
-    check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend_t), B, 3 * c.V, ptr(dcoef), ptr(ws2), stream()),
-          "smplr_blend_bwd")
     dx = _empty(tuple(x.shape), x) if out is None else out
     if x.shape[1] > num_cam + 82:
         dx.zero_()
-    check(lib.smplr_pose_bwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_dirs), ptr(c.parents), ptr(Rs),
-                             ptr(J), ptr(A), ptr(dcoef), ptr(dA), ptr(dJt), ptr(dcam), ptr(dx), stream()),
-          "smplr_pose_bwd")
+    ws = _workspace(lib.smplr_smpl_bwd_workspace(B, c.V), x)
+    check(lib.smplr_smpl_bwd(ptr(dverts), ptr(dproj), ptr(dJt), ptr(x), x.shape[1], num_cam, B, c.V, vs,
+                             ptr(c.blend_t), ptr(c.lbs_weights), ptr(c.J_dirs), ptr(c.parents), ptr(Rs), ptr(J),
+                             ptr(A), ptr(v_posed), ptr(dx), ptr(ws), stream()), "smplr_smpl_bwd")
     return dx
 
 

@@ -333,3 +333,42 @@ def test_concurrent_chunks_identical(smpl_model):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][2], outs[1][2])
     grad_close(outs[1][3].cpu().numpy(), outs[0][3].cpu().numpy(), 1e-5, "dx chunks vs whole")
+
+
+def test_joints_output(layer, smpl_model):
+    """Optional cocoplus/lsp joints (batch_smpl.py:147-151, commented out in the reference)."""
+    x = t(make_x(2, 48, seed=81))
+    verts = layer(x)
+    j = layer.joints(verts)
+    assert j.shape == (2, 14, 3)
+    want = np.einsum("bvc,jv->bjc", verts.cpu().numpy().astype(np.float64), smpl_model.cocoplus_regressor[:14])
+    assert np.abs(j.cpu().numpy() - want).max() < 1e-5
+
+
+def test_granular_backward_chain_equals_fused(smpl_model):
+    """smplr_skin_bwd -> smplr_blend_bwd -> smplr_pose_bwd (the stand-alone entry points) give the same
+    dx as the fused smplr_smpl_bwd the autograd nodes use."""
+    from ilps_amd import ops, _lib
+    from ilps_amd._lib import ptr, stream, check
+    lib = _lib.load()
+    d = dev()
+    c = ops.SMPLConstants.from_model(smpl_model, d)
+    B, V = 37, c.V
+    x = t(make_x(B, 48, seed=91))
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
+    v_posed = ops._blend_fwd(coef, c)
+    rng = np.random.default_rng(2)
+    dverts, dproj, dJt = t(rng.normal(0, 1, (B, V, 3))), t(rng.normal(0, 1, (B, V, 3))), t(rng.normal(0, 1, (B, 24, 3)))
+    fused = ops._smpl_bwd(x, 4, c, Rs, J, A, v_posed, dverts, dproj, dJt)
+    dv_posed, dA, dcam = torch.empty(B, V, 3, device=d), torch.empty(B, 24, 12, device=d), torch.empty(B, 4, device=d)
+    ws = torch.empty(lib.smplr_skin_bwd_workspace(B, V) // 4 + 1, device=d)
+    check(lib.smplr_skin_bwd(ptr(dverts), ptr(dproj), ptr(v_posed), ptr(c.lbs_weights), ptr(A), ptr(x), 86, B, V, 1,
+                             ptr(dv_posed), ptr(dA), ptr(dcam), ptr(ws), stream()), "skin_bwd")
+    dcoef = torch.empty(B, 220, device=d)
+    ws2 = torch.empty(lib.smplr_blend_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
+    check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend_t), B, 3 * V, ptr(dcoef), ptr(ws2), stream()), "blend_bwd")
+    dx = torch.empty(B, 86, device=d)
+    check(lib.smplr_pose_bwd(ptr(x), 86, 4, B, ptr(c.J_dirs), ptr(c.parents), ptr(Rs), ptr(J), ptr(A), ptr(dcoef),
+                             ptr(dA), ptr(dJt), ptr(dcam), ptr(dx), stream()), "pose_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dx, fused)          # same kernels, same summation order
