@@ -425,17 +425,18 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
   float *dp = dproj + (size_t)n * VP * 3;
   const int ch = tid & 31, strip = tid >> 5;
   const int ro = blockIdx.x * SB_ROWS + strip;            // output (flipped) row of this strip
+  const int cbeg = 0, cend = W;
   if (ro < W) {
     const float fr = (float)(W - 1 - ro);
     const size_t row0 = (size_t)n * npix + (size_t)ro * W;
     int cur = -1;
     float sx = 0.0f, sy = 0.0f;
-    for (int c0 = 0; c0 < W; c0 += SB_U) {
+    for (int c0 = cbeg; c0 < cend; c0 += SB_U) {
       int a[SB_U];
       float g[SB_U];
 #pragma unroll
       for (int u = 0; u < SB_U; ++u) {
-        const int cc = (c0 + u < W) ? c0 + u : W - 1;
+        const int cc = (c0 + u < cend) ? c0 + u : cend - 1;
         const size_t po = row0 + cc;
         a[u] = arg[po * 32 + ch];
         g[u] = dseg[po * C + min(ch, C - 1)];       // unconditional load (slots >= C are masked below)
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
         const int gate = __shfl(a[u], 0, 32);     // channel-0 lane of this pixel: 1 = clip passes gradient
         const float g0 = __shfl(g[u], 0, 32);
         g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
-        if (!(ch >= 1 && ch < C && c0 + u < W)) a[u] = -1;
+        if (!(ch >= 1 && ch < C && c0 + u < cend)) a[u] = -1;
         rv[u] = R[a[u] >= 0 ? a[u] : 0];
       }
 #pragma unroll

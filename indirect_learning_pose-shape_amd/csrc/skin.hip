@@ -17,7 +17,7 @@ namespace smplr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SK_MB = 4;       // meshes per thread in the forward (weights stay in registers)
+constexpr int SK_MB = 1;       // meshes per thread in the forward (weights stay in registers)
 constexpr int SKB_T = 256;     // backward block: 256 vertices (4 waves)
 constexpr int SKB_WLD = 25;    // LDS stride of a vertex' 24 weights (odd: conflict-free)
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
 // One block = 256 vertices x SKB_MB meshes (the 24 skinning weights of a vertex are loaded once and
 // kept in registers / LDS for all of them).  part layout per (mesh, block): 288 dA + 4 dcam floats.
 constexpr int SKB_PART = 292;
-constexpr int SKB_MB = 4;
+constexpr int SKB_MB = 1;
 
 __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
