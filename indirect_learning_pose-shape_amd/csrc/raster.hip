@@ -228,8 +228,9 @@ __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
 __device__ __forceinline__ float fast_exp_neg(float x) { return __expf(-x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-constexpr int HC = 16;    // channels per half
-constexpr int TLD = 17;   // tile row stride
+constexpr int HC = 8;     // channels per wave (channel group)
+constexpr int TLD = 9;    // tile row stride
+constexpr int NG = 4;     // channel groups = waves per 64-pixel group
 
 // One vertex against this lane's pixel: strict '<' keeps the first arg-min in list order.
 #define SMPLR_PAIR(rec, slot)                                   \
@@ -266,23 +267,32 @@ __device__ __forceinline__ void swait_group(f32x16s &v) {
   SMPLR_PAIR(make_float4(grp[8], grp[9], grp[10], grp[11]), (k) + 2)               \
   SMPLR_PAIR(make_float4(grp[12], grp[13], grp[14], grp[15]), (k) + 3)
 
-__global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict__ G,
-                                                        const int *__restrict__ goff,
-                                                        const int *__restrict__ lstart,
-                                                        const uint2 *__restrict__ lrec, int P, int K,
-                                                        int S, int W, int B, int ntiles,
-                                                        float *__restrict__ seg, short *__restrict__ arg) {
-  __shared__ float sS[RT * TLD];
-  __shared__ short sA[RT * TLD];
+// Block = 256 pixels of one mesh x 4 channel groups = 16 waves: wave (g, w) evaluates channels
+// [8g, 8g+8) for pixels [64w, 64w+64) of the tile.  What bounds this kernel at small batch is the
+// per-wave dependent chain (scalar loads -> VALU -> exp -> LDS, part after part), so the 32 channels
+// are spread over 4 waves instead of walked by one; the background channel needs the sum over all
+// parts, exchanged through LDS (fixed order).
+__global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
+                                                             const int *__restrict__ goff,
+                                                             const int *__restrict__ lstart,
+                                                             const uint2 *__restrict__ lrec, int P, int K,
+                                                             int S, int W, int B, int ntiles,
+                                                             float *__restrict__ seg, short *__restrict__ arg) {
+  __shared__ float sS[NG * RT * TLD];
+  __shared__ short sA[NG * RT * TLD];
+  __shared__ float sSum[NG][RT];
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, idx = bid >> 3;
   const int n = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
-  if (n >= B) return;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (n >= B) return;                                    // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
+  const int g = wave >> 2, pw = wave & 3;                // channel group, pixel sub-tile
+  const int pt = pw * 64 + lane;                         // pixel within the tile
   const int npix = W * W;
-  const int q = tile * RT + tid;
+  const int q = tile * RT + pt;
   const int qc = q < npix ? q : npix - 1;
   const int r = qc / W, c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
@@ -292,12 +302,11 @@ __global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict
   const int l0 = lstart[(size_t)n * (npix + 1) + qc], l1 = lstart[(size_t)n * (npix + 1) + qc + 1];
   const uint2 *lrecn = lrec + (size_t)n * K;
   const int lbase = goffn[P];
-  float *myS = &sS[tid * TLD];
-  short *myA = &sA[tid * TLD];
+  float *myS = &sS[(g * RT + pt) * TLD];
+  short *myA = &sA[(g * RT + pt) * TLD];
+  const int ch0 = g * HC;
 
-  float sum = 0.0f;
-  for (int half = 1; half >= 0; --half) {
-    const int ch0 = half * HC;
+  {
     const int p_first = (ch0 == 0) ? 0 : ch0 - 1;
     int beg = goffn[p_first < P ? p_first : P];
     int nxt = goffn[(p_first + 1) < P ? (p_first + 1) : P];     // end of the current part
@@ -332,52 +341,56 @@ __global__ __launch_bounds__(RT) void raster_fwd_kernel(const float4 *__restrict
       myA[j] = (short)bslot;
       beg = end;
     }
-    // merge this pixel's local records (invisible vertices that round to this pixel)
-    for (int i = l0; i < l1; ++i) {
-      const uint2 rec = lrecn[i];
-      const int ch = 1 + (int)rec.y;
-      if (ch >= ch0 && ch < ch0 + HC) {
-        const float sc = fast_exp_neg(__uint_as_float(rec.x));
-        const int j = ch - ch0;
-        if (sc > myS[j]) {                                   // ties keep the earlier (global) winner
-          myS[j] = sc;
-          myA[j] = (short)(lbase + i);
-        }
+  }
+  // merge this pixel's local records (invisible vertices that round to this pixel)
+  for (int i = l0; i < l1; ++i) {
+    const uint2 rec = lrecn[i];
+    const int ch = 1 + (int)rec.y;
+    if (ch >= ch0 && ch < ch0 + HC) {
+      const float sc = fast_exp_neg(__uint_as_float(rec.x));
+      const int j = ch - ch0;
+      if (sc > myS[j]) {                                   // ties keep the earlier (global) winner
+        myS[j] = sc;
+        myA[j] = (short)(lbase + i);
       }
     }
-    for (int j = 0; j < HC; ++j) sum += myS[j];          // slot of channel 0 holds 0 here
-    if (half == 0) {
-      myS[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);     // background (:61-64)
-      myA[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;     // clip pass-through gate
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): tile writes done
-    __builtin_amdgcn_wave_barrier();
-    // write this half: 64 pixels x 16 channels; lane -> (pixel, 4-channel group)
-    const int q0 = tile * RT + wave * 64;
+  }
+  {
+    float part = 0.0f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int e = it * 64 + lane;
-      const int pl = e >> 2, c4 = (e & 3) * 4;
-      const int qq = q0 + pl;
-      if (qq < npix) {
-        const int rr = qq / W, cc = qq - rr * W;
-        const size_t o = ((size_t)n * W + (W - 1 - rr)) * W + cc;     // rows flipped (:68)
-        const float *ts = &sS[(wave * 64 + pl) * TLD + c4];
-        const short *ta = &sA[(wave * 64 + pl) * TLD + c4];
-        float *so = seg + o * C + ch0 + c4;
-        if (ch0 + c4 + 3 < C && (C & 3) == 0) {
-          *reinterpret_cast<float4 *>(so) = make_float4(ts[0], ts[1], ts[2], ts[3]);
-        } else {
-          for (int t = 0; t < 4; ++t)
-            if (ch0 + c4 + t < C) so[t] = ts[t];
-        }
-        short4 o4;
-        o4.x = ta[0]; o4.y = ta[1]; o4.z = ta[2]; o4.w = ta[3];
-        *reinterpret_cast<short4 *>(arg + o * 32 + ch0 + c4) = o4;
+    for (int j = 0; j < HC; ++j) part += myS[j];           // the slot of channel 0 holds 0 here
+    sSum[g][pt] = part;
+  }
+  __syncthreads();
+  if (g == 0) {
+    const float sum = ((sSum[3][pt] + sSum[2][pt]) + sSum[1][pt]) + sSum[0][pt];
+    myS[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
+    myA[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): tile writes done
+  __builtin_amdgcn_wave_barrier();
+  // write this wave's 64 pixels x 8 channels; lane -> (pixel, 4-channel half)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = it * 64 + lane;
+    const int pl = pw * 64 + (e >> 1), c4 = (e & 1) * 4;
+    const int qq = tile * RT + pl;
+    if (qq < npix && ch0 + c4 < C) {
+      const int rr = qq / W, cc = qq - rr * W;
+      const size_t o = ((size_t)n * W + (W - 1 - rr)) * W + cc;     // rows flipped (:68)
+      const float *ts = &sS[(g * RT + pl) * TLD + c4];
+      const short *ta = &sA[(g * RT + pl) * TLD + c4];
+      float *so = seg + o * C + ch0 + c4;
+      if (ch0 + c4 + 3 < C && (C & 3) == 0) {
+        *reinterpret_cast<float4 *>(so) = make_float4(ts[0], ts[1], ts[2], ts[3]);
+      } else {
+        for (int t = 0; t < 4; ++t)
+          if (ch0 + c4 + t < C) so[t] = ts[t];
       }
+      short4 o4;
+      o4.x = ta[0]; o4.y = ta[1]; o4.z = ta[2]; o4.w = ta[3];
+      *reinterpret_cast<short4 *>(arg + o * 32 + ch0 + c4) = o4;
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -659,7 +672,7 @@ int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, co
   SMPLR_LAUNCH_CHECK("smplr_seg_fwd(bin)");
   const int ntiles = (W * W + RT - 1) / RT;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
-  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RT), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
+  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RT * NG), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
                      seg, reinterpret_cast<short *>(arg));
   SMPLR_LAUNCH_CHECK("smplr_seg_fwd");
   return 0;
