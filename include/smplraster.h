@@ -81,10 +81,13 @@ int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3,
  * (projection.py:54-81) as an optional epilogue.
  *   verts (B,V,3) = (sum_j w[v][j] A[b][j]) . [v_posed;1]
  *   proj  (B,VP,3) = (u0 + k_u x, v0 + k_v y, z) of vertices 0, vs, 2vs, ...  (NULL: skip)
- *   cam = x (row stride x_stride; columns 0..3 = k_u,k_v,u0,v0), may be NULL iff proj NULL. */
-int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *A,
-                   const float *cam, int x_stride, int B, int V, int vertex_sampling,
-                   float *verts, float *proj, void *stream);
+ *   cam = x (row stride x_stride; columns 0..3 = k_u,k_v,u0,v0), may be NULL iff proj NULL.
+ *   lbs_top4 (V,8) or NULL: per vertex its (up to) 4 non-zero weights followed by their joint
+ *   indices as floats - the sparse form of lbs_weights (real SMPL rows have <= 4 non-zeros);
+ *   when given, T sums 4 terms instead of 24, bit-identically (zero terms add exactly 0).      */
+int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *lbs_top4,
+                   const float *A, const float *cam, int x_stride, int B, int V,
+                   int vertex_sampling, float *verts, float *proj, void *stream);
 
 /* Backward of skinning (+ projection epilogue).
  *   dverts (B,V,3) or NULL;  dproj (B,VP,3) or NULL (the rasterisers write its z column as 0:
@@ -93,9 +96,10 @@ int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *
  *   workspace: smplr_skin_bwd_workspace(B,V) bytes (per-block partials, summed in fixed order). */
 size_t smplr_skin_bwd_workspace(int B, int V);
 int smplr_skin_bwd(const float *dverts, const float *dproj,
-                   const float *v_posed, const float *lbs_weights, const float *A,
-                   const float *cam, int x_stride, int B, int V, int vertex_sampling,
-                   float *dv_posed, float *dA, float *dcam, void *workspace, void *stream);
+                   const float *v_posed, const float *lbs_weights, const float *lbs_top4,
+                   const float *A, const float *cam, int x_stride, int B, int V,
+                   int vertex_sampling, float *dv_posed, float *dA, float *dcam, void *workspace,
+                   void *stream);
 
 /* Fused backward of the whole SMPLLayer (+ projection epilogue): smplr_skin_bwd -> smplr_blend_bwd ->
  * smplr_pose_bwd in three launches, the partial sums of the first two folded into the third
@@ -104,8 +108,8 @@ int smplr_skin_bwd(const float *dverts, const float *dproj,
 size_t smplr_smpl_bwd_workspace(int B, int V);
 int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed,
                    const float *x, int x_stride, int num_cam, int B, int V, int vertex_sampling,
-                   const float *blend_t, const float *lbs_weights, const float *J_dirs,
-                   const int32_t *parents, const float *Rs, const float *J, const float *A,
+                   const float *blend_t, const float *lbs_weights, const float *lbs_top4,
+                   const float *J_dirs, const int32_t *parents, const float *Rs, const float *J, const float *A,
                    const float *v_posed, float *dx, void *workspace, void *stream);
 
 /* ---- orthographic_project: keras_smpl/projection.py:54-81 ------------------------------ */

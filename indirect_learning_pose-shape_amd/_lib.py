@@ -30,11 +30,11 @@ SIGNATURES = {
     "smplr_blend_fwd": (c_int, [P, P, P, I, I, P, P]),
     "smplr_blend_bwd_workspace": (c_size_t, [I, I]),
     "smplr_blend_bwd": (c_int, [P, P, I, I, P, P, P]),
-    "smplr_skin_fwd": (c_int, [P, P, P, P, I, I, I, I, P, P, P]),
+    "smplr_skin_fwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P]),
     "smplr_skin_bwd_workspace": (c_size_t, [I, I]),
-    "smplr_skin_bwd": (c_int, [P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
+    "smplr_skin_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "smplr_smpl_bwd_workspace": (c_size_t, [I, I]),
-    "smplr_smpl_bwd": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
+    "smplr_smpl_bwd": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "smplr_project_fwd": (c_int, [P, P, I, I, I, I, P, P]),
     "smplr_project_bwd": (c_int, [P, P, P, I, I, I, I, P, P, P]),
     "smplr_visibility": (c_int, [P, I, I, I, I, P, P]),

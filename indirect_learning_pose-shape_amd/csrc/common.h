@@ -48,8 +48,8 @@ int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B
                               hipStream_t st);
 int skin_bwd_nblk(int V);
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
-                             const float *lbs_weights, const float *A, const float *cam, int x_stride, int B,
-                             int V, int vs, float *dv_posed, float *part, hipStream_t st);
+                             const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
+                             int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st);
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -360,7 +360,7 @@ size_t smplr_smpl_bwd_workspace(int B, int V) {
 
 int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed, const float *x,
                    int x_stride, int num_cam, int B, int V, int vertex_sampling, const float *blend_t,
-                   const float *lbs_weights, const float *J_dirs, const int32_t *parents, const float *Rs,
+                   const float *lbs_weights, const float *lbs_top4, const float *J_dirs, const int32_t *parents, const float *Rs,
                    const float *J, const float *A, const float *v_posed, float *dx, void *workspace,
                    void *stream) {
   using namespace smplr;
@@ -379,7 +379,7 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_tran
   float *skin_part = reinterpret_cast<float *>(base + align256((size_t)B * V * 3 * sizeof(float)));
   float *blend_part = reinterpret_cast<float *>(reinterpret_cast<char *>(skin_part) +
                                                 align256((size_t)B * skin_bwd_nblk(V) * 292 * sizeof(float)));
-  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, A, dproj ? x : nullptr, x_stride, B, V,
+  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, lbs_top4, A, dproj ? x : nullptr, x_stride, B, V,
                                     vertex_sampling, dv_posed, skin_part, st);
   if (rc) return rc;
   rc = launch_blend_bwd_partials(dv_posed, blend_t, B, 3 * V, blend_part, st);

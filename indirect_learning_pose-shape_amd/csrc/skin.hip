@@ -21,18 +21,31 @@ constexpr int SK_MB = 1;       // meshes per thread in the forward (weights stay
 constexpr int SKB_T = 256;     // backward block: 256 vertices (4 waves)
 constexpr int SKB_WLD = 25;    // LDS stride of a vertex' 24 weights (odd: conflict-free)
 
+// top4 (V,8): per vertex its (up to) 4 non-zero skinning weights and their joint indices (as floats),
+// or NULL.  Real SMPL rows have <= 4 non-zeros, so T = sum_j w_j A_j needs 4 x 12 FMAs, not 24 x 12;
+// dropping exact-zero terms in index order leaves every fp32 result bit-identical.  Rows with more
+// non-zeros make the host pass NULL and the dense path runs.
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__ v_posed,
                                                        const float *__restrict__ lbs,
+                                                       const float *__restrict__ top4,
                                                        const float *__restrict__ A,
                                                        const float *__restrict__ cam, int x_stride,
                                                        int B, int V, int vs, int VP,
                                                        float *__restrict__ verts,
                                                        float *__restrict__ proj) {
+  __shared__ float4 sAj[SPARSE ? 72 : 1];
   const int v = blockIdx.x * 256 + threadIdx.x;
   const bool live = v < V;
   const int vc = live ? v : V - 1;
-  float w[24];
-  {
+  float w[SPARSE ? 4 : 24];
+  int jx[4] = {0, 0, 0, 0};
+  if (SPARSE) {
+    const float4 *tp = reinterpret_cast<const float4 *>(top4 + (size_t)vc * 8);
+    const float4 ww = tp[0], jj = tp[1];
+    w[0] = ww.x; w[1] = ww.y; w[2] = ww.z; w[3] = ww.w;
+    jx[0] = (int)jj.x; jx[1] = (int)jj.y; jx[2] = (int)jj.z; jx[3] = (int)jj.w;
+  } else {
     const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -49,10 +62,24 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+    if (SPARSE) {
+      if (mi > 0) __syncthreads();
+      if (threadIdx.x < 72) sAj[threadIdx.x] = reinterpret_cast<const float4 *>(An)[threadIdx.x];
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 24; ++j)
+      for (int k = 0; k < 4; ++k) {
+        const float4 r0 = sAj[jx[k] * 3], r1 = sAj[jx[k] * 3 + 1], r2 = sAj[jx[k] * 3 + 2];
+        const float wj = w[k];
+        T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
+        T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
+        T[8] = fmaf(wj, r2.x, T[8]); T[9] = fmaf(wj, r2.y, T[9]); T[10] = fmaf(wj, r2.z, T[10]); T[11] = fmaf(wj, r2.w, T[11]);
+      }
+    } else {
 #pragma unroll
-      for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
+      for (int j = 0; j < 24; ++j)
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
+    }
     const float *vp = v_posed + ((size_t)n * V + vc) * 3;
     const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
     const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
@@ -79,9 +106,11 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
 constexpr int SKB_PART = 292;
 constexpr int SKB_MB = 1;
 
+template <bool SPARSE>
 __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
-    const float *__restrict__ lbs, const float *__restrict__ A, const float *__restrict__ cam,
+    const float *__restrict__ lbs, const float *__restrict__ top4, const float *__restrict__ A,
+    const float *__restrict__ cam,
     int x_stride, int B, int V, int vs, int VP, float *__restrict__ dv_posed, float *__restrict__ part) {
   __shared__ float sG[SKB_T][4];    // g (3) per vertex
   __shared__ float sP[SKB_T][4];    // [v_posed;1]
@@ -106,6 +135,14 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   }
 #pragma unroll
   for (int j = 0; j < 24; ++j) sW[tid * SKB_WLD + j] = w[j];
+  float w4[4] = {0.f, 0.f, 0.f, 0.f};
+  int jx[4] = {0, 0, 0, 0};
+  if (SPARSE) {
+    const float4 *tp = reinterpret_cast<const float4 *>(top4 + (size_t)vc * 8);
+    const float4 ww = tp[0], jj = tp[1];
+    w4[0] = ww.x; w4[1] = ww.y; w4[2] = ww.z; w4[3] = ww.w;
+    jx[0] = (int)jj.x; jx[1] = (int)jj.y; jx[2] = (int)jj.z; jx[3] = (int)jj.w;
+  }
   __syncthreads();
 
   const int li = lane & 15, lk = lane >> 4;
@@ -123,8 +160,9 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.0f;
 #pragma unroll 4
-    for (int j = 0; j < 24; ++j) {
-      const float wj = sW[tid * SKB_WLD + j];
+    for (int jq = 0; jq < (SPARSE ? 4 : 24); ++jq) {
+      const int j = SPARSE ? jx[jq & 3] : jq;
+      const float wj = SPARSE ? w4[jq & 3] : sW[tid * SKB_WLD + jq];
       const float4 r0 = sAj[j * 3], r1 = sAj[j * 3 + 1], r2 = sAj[j * 3 + 2];
       T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
       T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
@@ -251,11 +289,16 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restric
 int skin_bwd_nblk(int V) { return (V + SKB_T - 1) / SKB_T; }
 
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
-                             const float *lbs_weights, const float *A, const float *cam, int x_stride, int B,
-                             int V, int vs, float *dv_posed, float *part, hipStream_t st) {
+                             const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
+                             int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st) {
   const int VP = (V + vs - 1) / vs;
-  hipLaunchKernelGGL(skin_bwd_kernel, dim3(skin_bwd_nblk(V), (B + SKB_MB - 1) / SKB_MB), dim3(SKB_T), 0, st, dverts,
-                     dproj, v_posed, lbs_weights, A, cam, x_stride, B, V, vs, VP, dv_posed, part);
+  const dim3 grid(skin_bwd_nblk(V), (B + SKB_MB - 1) / SKB_MB);
+  if (lbs_top4)
+    hipLaunchKernelGGL(skin_bwd_kernel<true>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
+                       A, cam, x_stride, B, V, vs, VP, dv_posed, part);
+  else
+    hipLaunchKernelGGL(skin_bwd_kernel<false>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
+                       A, cam, x_stride, B, V, vs, VP, dv_posed, part);
   SMPLR_LAUNCH_CHECK("skin_bwd_kernel");
   return 0;
 }
@@ -266,9 +309,9 @@ extern "C" {
 
 static int check_vs(int V, int vs) { return vs >= 1 && vs <= V; }
 
-int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *A, const float *cam,
-                   int x_stride, int B, int V, int vertex_sampling, float *verts, float *proj,
-                   void *stream) {
+int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *lbs_top4, const float *A,
+                   const float *cam, int x_stride, int B, int V, int vertex_sampling, float *verts,
+                   float *proj, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && V > 0 && check_vs(V, vertex_sampling), "smplr_skin_fwd: bad sizes B=%d V=%d vs=%d",
                 B, V, vertex_sampling);
@@ -277,8 +320,12 @@ int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *
   SMPLR_REQUIRE(!proj || (cam && x_stride >= 4), "smplr_skin_fwd: proj requested without camera rows");
   const int VP = (V + vertex_sampling - 1) / vertex_sampling;
   dim3 grid((V + 255) / 256, (B + SK_MB - 1) / SK_MB);
-  hipLaunchKernelGGL(skin_fwd_kernel, grid, dim3(256), 0, as_stream(stream), v_posed, lbs_weights, A, cam,
-                     x_stride, B, V, vertex_sampling, VP, verts, proj);
+  if (lbs_top4)
+    hipLaunchKernelGGL(skin_fwd_kernel<true>, grid, dim3(256), 0, as_stream(stream), v_posed, lbs_weights, lbs_top4, A,
+                       cam, x_stride, B, V, vertex_sampling, VP, verts, proj);
+  else
+    hipLaunchKernelGGL(skin_fwd_kernel<false>, grid, dim3(256), 0, as_stream(stream), v_posed, lbs_weights, lbs_top4, A,
+                       cam, x_stride, B, V, vertex_sampling, VP, verts, proj);
   SMPLR_LAUNCH_CHECK("smplr_skin_fwd");
   return 0;
 }
@@ -290,7 +337,8 @@ size_t smplr_skin_bwd_workspace(int B, int V) {
 }
 
 int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed,
-                   const float *lbs_weights, const float *A, const float *cam, int x_stride, int B, int V,
+                   const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
+                   int x_stride, int B, int V,
                    int vertex_sampling, float *dv_posed, float *dA, float *dcam, void *workspace,
                    void *stream) {
   using namespace smplr;
@@ -301,8 +349,8 @@ int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed
   SMPLR_REQUIRE(dverts || dproj, "smplr_skin_bwd: need dverts and/or dproj");
   SMPLR_REQUIRE(!dproj || (cam && x_stride >= 4), "smplr_skin_bwd: dproj given without camera rows");
   const int nblk = skin_bwd_nblk(V);
-  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, A, cam, x_stride, B, V, vertex_sampling,
-                                    dv_posed, reinterpret_cast<float *>(workspace), as_stream(stream));
+  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, lbs_top4, A, cam, x_stride, B, V,
+                                    vertex_sampling, dv_posed, reinterpret_cast<float *>(workspace), as_stream(stream));
   if (rc) return rc;
   hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(B), dim3(320), 0, as_stream(stream),
                      reinterpret_cast<const float *>(workspace), nblk, dA, dcam);

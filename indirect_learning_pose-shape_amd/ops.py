@@ -38,6 +38,7 @@ class SMPLConstants:
     lbs_weights: torch.Tensor   # (V,24)
     parents: torch.Tensor       # (24,) int32
     joint_regressor: Optional[torch.Tensor] = None   # (V,19|14) cocoplus / lsp, optional
+    lbs_top4: Optional[torch.Tensor] = None   # (V,8) sparse form [w0..w3 | j0..j3] when every row has <= 4 non-zeros
 
     @staticmethod
     def from_model(model: SMPLModelData, device, joint_type: str = "lsp") -> "SMPLConstants":
@@ -54,6 +55,13 @@ class SMPLConstants:
         J_template = Jreg @ np.asarray(model.v_template, np.float64)        # (24,3)
         J_dirs = np.einsum("jv,vck->jck", Jreg, np.asarray(model.shapedirs, np.float64))
         f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(device)
+        w32 = np.asarray(model.weights, np.float32)
+        top4 = None
+        if int((w32 != 0).sum(axis=1).max()) <= 4:          # real SMPL: <= 4 influences per vertex
+            order = np.argsort(w32 == 0, axis=1, kind="stable")[:, :4]   # non-zero joints first, ascending
+            wv = np.take_along_axis(w32, order, 1)                      # padding slots carry weight 0
+            idx = np.where(wv != 0, order, 0)
+            top4 = f32(np.concatenate([wv, idx.astype(np.float32)], axis=1))
         jr = None
         if model.cocoplus_regressor is not None:
             jr = np.asarray(model.cocoplus_regressor, np.float64).T         # (V,19) :82-85
@@ -62,7 +70,7 @@ class SMPLConstants:
             jr = f32(jr)
         return SMPLConstants(
             V=V, v_template=f32(np.asarray(model.v_template).reshape(-1)), blend=f32(blend),
-            blend_t=f32(blend_t), J_template=f32(J_template), J_dirs=f32(J_dirs), lbs_weights=f32(model.weights),
+            blend_t=f32(blend_t), J_template=f32(J_template), J_dirs=f32(J_dirs), lbs_weights=f32(model.weights), lbs_top4=top4,
             parents=torch.as_tensor(np.asarray(model.parents, np.int32)).to(device),
             joint_regressor=jr)
 
@@ -139,7 +147,7 @@ def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_ve
     else:
         verts = _empty((B, c.V, 3), v_posed) if want_verts else None
         proj = _empty((B, (c.V + vs - 1) // vs, 3), v_posed) if cam is not None else None
-    check(lib.smplr_skin_fwd(ptr(v_posed), ptr(c.lbs_weights), ptr(A), ptr(cam),
+    check(lib.smplr_skin_fwd(ptr(v_posed), ptr(c.lbs_weights), ptr(c.lbs_top4), ptr(A), ptr(cam),
                              cam.shape[1] if cam is not None else 0, B, c.V, vs, ptr(verts), ptr(proj),
                              stream()), "smplr_skin_fwd")
     return verts, proj
@@ -156,7 +164,8 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
         dx.zero_()
     ws = _workspace(lib.smplr_smpl_bwd_workspace(B, c.V), x)
     check(lib.smplr_smpl_bwd(ptr(dverts), ptr(dproj), ptr(dJt), ptr(x), x.shape[1], num_cam, B, c.V, vs,
-                             ptr(c.blend_t), ptr(c.lbs_weights), ptr(c.J_dirs), ptr(c.parents), ptr(Rs), ptr(J),
+                             ptr(c.blend_t), ptr(c.lbs_weights), ptr(c.lbs_top4), ptr(c.J_dirs), ptr(c.parents),
+                             ptr(Rs), ptr(J),
                              ptr(A), ptr(v_posed), ptr(dx), ptr(ws), stream()), "smplr_smpl_bwd")
     return dx
 

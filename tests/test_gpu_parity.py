@@ -362,7 +362,8 @@ def test_granular_backward_chain_equals_fused(smpl_model):
     fused = ops._smpl_bwd(x, 4, c, Rs, J, A, v_posed, dverts, dproj, dJt)
     dv_posed, dA, dcam = torch.empty(B, V, 3, device=d), torch.empty(B, 24, 12, device=d), torch.empty(B, 4, device=d)
     ws = torch.empty(lib.smplr_skin_bwd_workspace(B, V) // 4 + 1, device=d)
-    check(lib.smplr_skin_bwd(ptr(dverts), ptr(dproj), ptr(v_posed), ptr(c.lbs_weights), ptr(A), ptr(x), 86, B, V, 1,
+    check(lib.smplr_skin_bwd(ptr(dverts), ptr(dproj), ptr(v_posed), ptr(c.lbs_weights), ptr(c.lbs_top4), ptr(A), ptr(x),
+                             86, B, V, 1,
                              ptr(dv_posed), ptr(dA), ptr(dcam), ptr(ws), stream()), "skin_bwd")
     dcoef = torch.empty(B, 220, device=d)
     ws2 = torch.empty(lib.smplr_blend_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
@@ -372,3 +373,23 @@ def test_granular_backward_chain_equals_fused(smpl_model):
                              ptr(dA), ptr(dJt), ptr(dcam), ptr(dx), stream()), "pose_bwd")
     torch.cuda.synchronize()
     assert torch.equal(dx, fused)          # same kernels, same summation order
+
+
+def test_sparse_and_dense_skinning_bit_identical(smpl_model):
+    """The <=4-influence fast path must equal the dense 24-joint path bit for bit, forward and backward."""
+    import dataclasses
+    from ilps_amd import ops
+    d = dev()
+    c = ops.SMPLConstants.from_model(smpl_model, d)
+    assert c.lbs_top4 is not None and c.lbs_top4.shape == (6890, 8)
+    cd = dataclasses.replace(c, lbs_top4=None)
+    x = t(make_x(9, 48, seed=95))
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
+    vp = ops._blend_fwd(coef, c)
+    v1, p1 = ops._skin_fwd(vp, A, c, cam=x)
+    v2, p2 = ops._skin_fwd(vp, A, cd, cam=x)
+    assert torch.equal(v1, v2) and torch.equal(p1, p2)
+    g = torch.randn_like(v1)
+    d1 = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, g, g, None)
+    d2 = ops._smpl_bwd(x, 4, cd, Rs, J, A, vp, g, g, None)
+    assert torch.equal(d1, d2)
