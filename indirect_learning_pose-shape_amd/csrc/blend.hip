@@ -40,21 +40,24 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
   {
     const int rows = min(4 * FW_BM, B - mbase);          // meshes present in this group
     const float *src = coef + (size_t)mbase * KP;        // contiguous rows*220 floats
-    // 28,160 contiguous floats, 110 per thread: 11 loads in flight, then their 11 LDS stores
+    // 28,160 contiguous floats, 110 per thread, in 2 batches of 55 loads in flight (a batch costs one
+    // memory round trip however many loads it holds); (mesh, k) of element e = tid + 256 u advance
+    // incrementally (256 = 220 + 36) instead of dividing per element
     const int nvalid = rows * KP;
-    for (int e0 = tid; e0 < 4 * FW_BM * KP; e0 += 256 * 11) {
-      float v[11];
+    int i = tid / KP, k = tid - i * KP;
+    for (int e0 = tid; e0 < 4 * FW_BM * KP; e0 += 256 * 55) {
+      float v[55];
 #pragma unroll
-      for (int u = 0; u < 11; ++u) {
+      for (int u = 0; u < 55; ++u) {
         const int e = e0 + u * 256;
         const float ld = src[min(e, nvalid - 1)];       // unconditional (clamped) load, select afterwards
         v[u] = (e < nvalid) ? ld : 0.0f;
       }
 #pragma unroll
-      for (int u = 0; u < 11; ++u) {
-        const int e = e0 + u * 256;
-        const int i = e / KP, k = e - i * KP;
+      for (int u = 0; u < 55; ++u) {
         sAall[(i >> 5) * (KP * A_LD) + k * A_LD + (i & 31)] = v[u];
+        k += 36; i += 1;
+        if (k >= KP) { k -= KP; i += 1; }
       }
     }
   }
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
   // B operand double-buffered in registers: batch q+1 (11 k-steps = 33 loads) is in flight while
   // the 33 MFMAs of batch q run, so one wave per SIMD is enough to cover the L2/HBM latency.
   constexpr int NB = 11;                       // k-steps per batch; 10 batches x 22 rows = 220
-  float b0[NB][3], b1[NB][3];
+  float b0[NB][3], b1[NB][3], b2[NB][3];
   auto load_batch = [&](float (&b)[NB][3], int kb) {
 #pragma unroll
     for (int s2 = 0; s2 < NB; ++s2) {
@@ -99,21 +102,28 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
       for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2][t], acc[t], 0, 0, 0);
     }
   };
-  // sched_barrier pins "issue the next batch's loads, then run this batch's MFMAs": left alone the
-  // scheduler sinks the loads next to their uses (8 in flight) and the loop stalls on L2 latency.
-  load_batch(b0, 0);
+  // Three B-operand batches rotate: batches q+1 and q+2 (66 loads) are in flight under batch q's
+  // 33 MFMAs (~1 us), which is what an L2-miss round trip takes.  sched_barrier pins the order:
+  // left alone the scheduler sinks the loads next to their uses (8 in flight) and the loop stalls.
+#define SMPLR_STEP(cur, nxt2, q)                                   \
+  if ((q) + 2 < 10) load_batch(nxt2, ((q) + 2) * 2 * NB);         \
+  __builtin_amdgcn_sched_barrier(0);                               \
+  mma_batch(cur, (q) * 2 * NB);                                    \
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < 10; q += 2) {
-    load_batch(b1, (q + 1) * 2 * NB);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_batch(b0, q * 2 * NB);
-    __builtin_amdgcn_sched_barrier(0);
-    if (q + 2 < 10) load_batch(b0, (q + 2) * 2 * NB);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_batch(b1, (q + 1) * 2 * NB);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  load_batch(b0, 0);
+  load_batch(b1, 2 * NB);
+  __builtin_amdgcn_sched_barrier(0);
+  SMPLR_STEP(b0, b2, 0)
+  SMPLR_STEP(b1, b0, 1)
+  SMPLR_STEP(b2, b1, 2)
+  SMPLR_STEP(b0, b2, 3)
+  SMPLR_STEP(b1, b0, 4)
+  SMPLR_STEP(b2, b1, 5)
+  SMPLR_STEP(b0, b2, 6)
+  SMPLR_STEP(b1, b0, 7)
+  SMPLR_STEP(b2, b1, 8)
+  SMPLR_STEP(b0, b2, 9)
+#undef SMPLR_STEP
 
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
