@@ -160,8 +160,8 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
 
 /* ---- projects_to_silhouette: keras_smpl/projects_to_silhouette.py:14-44 ----------------- */
 /* silh (B,W,W,2) = [1-s, s], s = max_v exp(-|proj_v-(c,r)|/1.2) over ALL VP vertices, rows
- * flipped; arg (B,W,W) int32 = maximising vertex.  workspace: smplr_silh_workspace(B,VP) B.  */
-size_t smplr_silh_workspace(int B, int VP);
+ * flipped; arg (B,W,W) int32 = maximising vertex.  workspace: smplr_silh_workspace(B,VP,W) B.  */
+size_t smplr_silh_workspace(int B, int VP, int W);
 int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg,
                    void *workspace, void *stream);
 int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg,

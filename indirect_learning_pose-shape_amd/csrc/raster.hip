@@ -571,6 +571,239 @@ __global__ __launch_bounds__(RT) void silh_fwd_kernel(const float4 *__restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pruned silhouette forward (exact).  Vertices are binned into 1-px cells (cell = rounded position,
+// on a window of the image plus SM px of margin; the rest are "outliers", always evaluated).  A
+// vertex lies within 0.7072 px of its cell centre, so if the nearest OCCUPIED cell centre is at
+// distance Dmin from a pixel, the nearest vertex is no farther than Dmin + 0.7072 and therefore
+// lives in a cell whose centre is within T = Dmin + 1.4143 of the pixel: pass 1 finds Dmin over the
+// ~650 occupied cells, pass 2 evaluates exactly only the vertices of cells within T.  Ties are
+// broken towards the lowest vertex index, as the dense formulation's arg-max does.
+constexpr int SM = 8;            // margin of the cell window around the image
+constexpr int SILH_WMAX = 96;    // (W + 16)^2 counters must fit LDS next to the scan scratch
+
+struct SilhWs {
+  size_t cl_off, sr_off, hdr_off, total;
+  int ccap, vcap;
+};
+static SilhWs silh_ws_layout(int B, int VP, int W) {
+  SilhWs w;
+  const int GW = W + 2 * SM;
+  w.ccap = ((GW * GW < VP ? GW * GW : VP) + 2 * GP + 3) / 4 * 4;   // occupied cells + padding + a spare sentinel group
+  // every occupied cell's vertex list is padded to a multiple of GP records, + one spare group
+  w.vcap = (VP + (GP - 1) * (GW * GW < VP ? GW * GW : VP) + 2 * GP + 3) / 4 * 4;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  w.cl_off = take((size_t)B * w.ccap * sizeof(float4));
+  w.sr_off = take((size_t)B * w.vcap * sizeof(float4));
+  w.hdr_off = take((size_t)B * sizeof(int4));
+  w.total = off;
+  return w;
+}
+
+__global__ __launch_bounds__(BIN_T) void silh_bin_kernel(const float *__restrict__ proj, int VP, int W, int ccap,
+                                                         int vcap, float4 *__restrict__ CL,
+                                                         float4 *__restrict__ SR, int4 *__restrict__ hdr) {
+  extern __shared__ int s_cnt[];   // GW*GW
+  __shared__ int s_wave[BIN_T / 64];
+  __shared__ int s_nout;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int GW = W + 2 * SM, cells = GW * GW;
+  const float *pj = proj + (size_t)n * VP * 3;
+  float4 *CLn = CL + (size_t)n * ccap;
+  float4 *SRn = SR + (size_t)n * vcap;
+  for (int i = tid; i < cells; i += BIN_T) s_cnt[i] = 0;
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+  float pu[IPT_MAX], pv[IPT_MAX];
+  int pc[IPT_MAX];
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int v = tid + j * BIN_T;
+    pc[j] = -2;                                  // no vertex
+    if (v < VP) {
+      pu[j] = pj[v * 3];
+      pv[j] = pj[v * 3 + 1];
+      const float cx = rintf(pu[j]) + (float)SM, cy = rintf(pv[j]) + (float)SM;
+      if (cx >= 0.0f && cx < (float)GW && cy >= 0.0f && cy < (float)GW) {
+        pc[j] = (int)cy * GW + (int)cx;
+        atomicAdd(&s_cnt[pc[j]], 1);
+      } else {
+        pc[j] = -1;                              // outlier (also NaN positions)
+        atomicAdd(&s_nout, 1);
+      }
+    }
+  }
+  __syncthreads();
+  // per cell: start offset (exclusive scan of counts) and index among the occupied cells
+  const int ept = (cells + BIN_T - 1) / BIN_T;
+  const int e0 = tid * ept, e1 = min(cells, e0 + ept);
+  int lc = 0, lo = 0;
+  for (int e = e0; e < e1; ++e) { const int c = s_cnt[e]; lc += (c + GP - 1) / GP * GP; lo += (c > 0); }
+  int tot_v, tot_c;
+  int run_v = block_excl_scan(lc, s_wave, &tot_v);
+  int run_c = block_excl_scan(lo, s_wave, &tot_c);
+  for (int e = e0; e < e1; ++e) {
+    const int c = s_cnt[e];
+    const int cp = (c + GP - 1) / GP * GP;        // records incl. padding
+    if (c > 0) {
+      const int cy = e / GW, cx = e - cy * GW;
+      CLn[run_c++] = make_float4((float)(cx - SM), (float)(cy - SM), __int_as_float(run_v), __int_as_float(cp));
+      for (int i = run_v + c; i < run_v + cp; ++i)   // sentinels: far away, never win (index = INT_MAX)
+        SRn[i] = make_float4(1e9f, 1e9f, __int_as_float(0x7fffffff), 0.0f);
+    }
+    s_cnt[e] = run_v;                            // placement cursor
+    run_v += cp;
+  }
+  // sentinel cells: pad to a multiple of GP plus one spare group (the stream prefetches one past)
+  if (tid < 2 * GP) {
+    const int padded = (tot_c + GP - 1) / GP * GP + GP;
+    const int i = tot_c + tid;
+    if (i < padded && i < ccap) CLn[i] = make_float4(1e9f, 1e9f, __int_as_float(0), __int_as_float(0));
+  }
+  __syncthreads();
+  if (tid == 0) hdr[n] = make_int4(tot_c, tot_v, s_nout, 0);
+  __syncthreads();
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int v = tid + j * BIN_T;
+    if (pc[j] >= 0) {
+      const int dst = atomicAdd(&s_cnt[pc[j]], 1);
+      SRn[dst] = make_float4(pu[j], pv[j], __int_as_float(v), 0.0f);
+    } else if (pc[j] == -1) {
+      const int dst = tot_v + atomicAdd(&s_nout, 1);
+      SRn[dst] = make_float4(pu[j], pv[j], __int_as_float(v), 0.0f);
+    }
+  }
+}
+
+#define SMPLR_SILH_EVAL(rec, ok)                                                      \
+  {                                                                                   \
+    const float du_ = (rec).x - fc, dv_ = (rec).y - fr;                               \
+    const float key_ = fmaf(du_, du_, dv_ * dv_);                                     \
+    const int id_ = __float_as_int((rec).z);                                          \
+    if ((ok) && (key_ < best || (key_ == best && id_ < bidx))) { best = key_; bidx = id_; } \
+  }
+
+__global__ __launch_bounds__(RT) void silh_fwd_pruned_kernel(const float4 *__restrict__ CL,
+                                                             const float4 *__restrict__ SR,
+                                                             const int4 *__restrict__ hdr, int ccap, int vcap,
+                                                             int W, float *__restrict__ out,
+                                                             int *__restrict__ arg_out) {
+  const int n = blockIdx.y;
+  const int q = blockIdx.x * RT + threadIdx.x;
+  const int npix = W * W;
+  const bool live = q < npix;
+  const int qc = live ? q : npix - 1;
+  const int r = qc / W, c = qc - r * W;
+  const float fc = (float)c, fr = (float)r;
+  const float4 *CLn = CL + (size_t)n * ccap;
+  const float4 *SRn = SR + (size_t)n * vcap;
+  const int4 h = hdr[n];
+  const int ncells = __builtin_amdgcn_readfirstlane(h.x), out_start = __builtin_amdgcn_readfirstlane(h.y),
+            nout = __builtin_amdgcn_readfirstlane(h.z);
+  const int kend = (ncells + GP - 1) / GP * GP;
+  // pass 1: squared distance to the nearest occupied cell centre (cells stream as scalar operands)
+  float dmin2 = INFINITY;
+  if (kend > 0) {
+    f32x16s ga, gb;
+    const float4 *gp = CLn;
+    sload_group(ga, gp);
+    swait_group(ga);
+    int k = 0;
+#define SMPLR_CELL_D2(g, j) fmaf((g)[4 * (j)] - fc, (g)[4 * (j)] - fc, ((g)[4 * (j) + 1] - fr) * ((g)[4 * (j) + 1] - fr))
+    while (true) {
+      sload_group(gb, gp + GP);
+      dmin2 = fminf(fminf(dmin2, SMPLR_CELL_D2(ga, 0)), fminf(SMPLR_CELL_D2(ga, 1), fminf(SMPLR_CELL_D2(ga, 2), SMPLR_CELL_D2(ga, 3))));
+      swait_group(gb);
+      k += GP;
+      if (k >= kend) break;
+      sload_group(ga, gp + 2 * GP);
+      dmin2 = fminf(fminf(dmin2, SMPLR_CELL_D2(gb, 0)), fminf(SMPLR_CELL_D2(gb, 1), fminf(SMPLR_CELL_D2(gb, 2), SMPLR_CELL_D2(gb, 3))));
+      swait_group(ga);
+      k += GP;
+      gp += 2 * GP;
+      if (k >= kend) break;
+    }
+  }
+  const float T = sqrtf(dmin2) + 1.4143f;
+  const float T2 = (dmin2 < 1e17f) ? T * T * 1.0001f : -1.0f;
+  // pass 2: exact evaluation of the vertices of every cell whose centre is within T
+  float best = INFINITY;
+  int bidx = 0x7fffffff;
+#define SMPLR_SILH_GROUP(g)                                                                         \
+  SMPLR_SILH_EVAL(make_float4((g)[0], (g)[1], (g)[2], 0.f), cand)                                   \
+  SMPLR_SILH_EVAL(make_float4((g)[4], (g)[5], (g)[6], 0.f), cand)                                   \
+  SMPLR_SILH_EVAL(make_float4((g)[8], (g)[9], (g)[10], 0.f), cand)                                  \
+  SMPLR_SILH_EVAL(make_float4((g)[12], (g)[13], (g)[14], 0.f), cand)
+  // one cell: candidate test; its records (padded to whole groups) stream as scalar operands
+#define SMPLR_SILH_CELL(cg, j)                                                                      \
+  {                                                                                                 \
+    const float dx_ = (cg)[4 * (j)] - fc, dy_ = (cg)[4 * (j) + 1] - fr;                             \
+    const bool cand = fmaf(dx_, dx_, dy_ * dy_) <= T2;                                              \
+    if (__any(cand)) {                                                                              \
+      const int st_ = __builtin_amdgcn_readfirstlane(__float_as_int((cg)[4 * (j) + 2]));            \
+      const int cp_ = __builtin_amdgcn_readfirstlane(__float_as_int((cg)[4 * (j) + 3]));            \
+      f32x16s va, vb;                                                                               \
+      const float4 *vp_ = SRn + st_;                                                                \
+      sload_group(va, vp_);                                                                         \
+      swait_group(va);                                                                              \
+      int jj_ = 0;                                                                                  \
+      while (true) {                                                                                \
+        sload_group(vb, vp_ + GP);                                                                  \
+        SMPLR_SILH_GROUP(va)                                                                        \
+        swait_group(vb);                                                                            \
+        jj_ += GP;                                                                                  \
+        if (jj_ >= cp_) break;                                                                      \
+        sload_group(va, vp_ + 2 * GP);                                                              \
+        SMPLR_SILH_GROUP(vb)                                                                        \
+        swait_group(va);                                                                            \
+        jj_ += GP;                                                                                  \
+        vp_ += 2 * GP;                                                                              \
+        if (jj_ >= cp_) break;                                                                      \
+      }                                                                                             \
+    }                                                                                               \
+  }
+  if (kend > 0) {
+    f32x16s ca, cb;
+    const float4 *gp = CLn;
+    sload_group(ca, gp);
+    swait_group(ca);
+    int k = 0;
+    while (true) {
+      sload_group(cb, gp + GP);
+      swait_group(cb);          // the cells' inner streams use lgkmcnt too: keep this group's wait simple
+      SMPLR_SILH_CELL(ca, 0) SMPLR_SILH_CELL(ca, 1) SMPLR_SILH_CELL(ca, 2) SMPLR_SILH_CELL(ca, 3)
+      k += GP;
+      if (k >= kend) break;
+      sload_group(ca, gp + 2 * GP);
+      swait_group(ca);
+      SMPLR_SILH_CELL(cb, 0) SMPLR_SILH_CELL(cb, 1) SMPLR_SILH_CELL(cb, 2) SMPLR_SILH_CELL(cb, 3)
+      k += GP;
+      gp += 2 * GP;
+      if (k >= kend) break;
+    }
+  }
+  for (int j = out_start; j < out_start + nout; ++j) {                // outliers: always
+    const float4 rec = SRn[j];
+    SMPLR_SILH_EVAL(rec, true)
+  }
+  float score = 0.0f;
+  int pos = -1;
+  if (best < INFINITY) {
+    score = expf(-sqrtf(best) / 1.2f);
+    pos = bidx;
+  }
+  if (live) {
+    const size_t o = ((size_t)n * W + (W - 1 - r)) * W + c;   // rows flipped (:42)
+    out[o * 2 + 0] = 1.0f - score;
+    out[o * 2 + 1] = score;
+    arg_out[o] = pos;
+  }
+}
+
 __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict__ dsilh,
                                                         const float *__restrict__ silh,
                                                         const int *__restrict__ arg,
@@ -705,10 +938,12 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
   return 0;
 }
 
-size_t smplr_silh_workspace(int B, int VP) {
-  if (B <= 0 || VP <= 0) return 0;
+size_t smplr_silh_workspace(int B, int VP, int W) {
+  if (B <= 0 || VP <= 0 || W <= 0) return 0;
   const int KP = (VP + smplr::CH - 1) / smplr::CH * smplr::CH;
-  return (size_t)B * KP * 4 * sizeof(float);
+  const size_t brute = (size_t)B * KP * 4 * sizeof(float);
+  const size_t pruned = (W <= smplr::SILH_WMAX && VP <= smplr::BIN_T * smplr::IPT_MAX) ? smplr::silh_ws_layout(B, VP, W).total : 0;
+  return brute > pruned ? brute : pruned;
 }
 
 int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg, void *workspace,
@@ -717,8 +952,25 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
   SMPLR_REQUIRE(B >= 0 && VP > 0 && W > 0 && W <= 1024, "smplr_silh_fwd: bad sizes B=%d VP=%d W=%d", B, VP, W);
   if (B == 0) return 0;
   SMPLR_REQUIRE(proj && silh && arg && workspace, "smplr_silh_fwd: null pointer");
-  const int KP = (VP + CH - 1) / CH * CH;
   hipStream_t st = as_stream(stream);
+  if (W <= SILH_WMAX && VP <= BIN_T * IPT_MAX) {
+    const SilhWs ws = silh_ws_layout(B, VP, W);
+    char *base = reinterpret_cast<char *>(workspace);
+    float4 *CL = reinterpret_cast<float4 *>(base + ws.cl_off);
+    float4 *SR = reinterpret_cast<float4 *>(base + ws.sr_off);
+    int4 *hdr = reinterpret_cast<int4 *>(base + ws.hdr_off);
+    const int GW = W + 2 * SM;
+    const size_t lds = (size_t)GW * GW * sizeof(int);
+    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bin_kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(silh_bin_kernel, dim3(B), dim3(BIN_T), lds, st, proj, VP, W, ws.ccap, ws.vcap, CL, SR, hdr);
+    SMPLR_LAUNCH_CHECK("smplr_silh_fwd(bin)");
+    hipLaunchKernelGGL(silh_fwd_pruned_kernel, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st, CL, SR, hdr, ws.ccap,
+                       ws.vcap, W, silh, arg);
+    SMPLR_LAUNCH_CHECK("smplr_silh_fwd");
+    return 0;
+  }
+  const int KP = (VP + CH - 1) / CH * CH;
   hipLaunchKernelGGL(silh_prep_kernel, dim3((KP + 255) / 256, B), dim3(256), 0, st, proj, VP, KP,
                      reinterpret_cast<float4 *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_silh_fwd(prep)");

@@ -228,7 +228,7 @@ def _silh_fwd(proj, W, out=None):
     else:
         silh = _empty((B, W, W, 2), proj)
         arg = _empty((B, W, W), proj, torch.int32)
-    ws = _workspace(lib.smplr_silh_workspace(B, VP), proj)
+    ws = _workspace(lib.smplr_silh_workspace(B, VP, W), proj)
     check(lib.smplr_silh_fwd(ptr(proj), B, VP, W, ptr(silh), ptr(arg), ptr(ws), stream()), "smplr_silh_fwd")
     return silh, arg
 
