@@ -393,3 +393,53 @@ def test_sparse_and_dense_skinning_bit_identical(smpl_model):
     d1 = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, g, g, None)
     d2 = ops._smpl_bwd(x, 4, cd, Rs, J, A, vp, g, g, None)
     assert torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("mask_kind", ["ones", "mixed"])
+def test_seg_generic_masks_and_odd_width(layer, part_tables, mask_kind):
+    """W = 50 (not a multiple of the 256-pixel tile) and user-supplied masks: all ones makes every
+    vertex far-reaching (6 972 record slots > the backward's 4 096 LDS slots: overflow path), 'mixed'
+    uses arbitrary positive values on both sides of the reach threshold."""
+    from ilps_amd.keras_smpl.projects_to_seg import projects_to_seg
+    from oracle import np_oracle as o
+    from oracle import torch_oracle as to
+    W = 50
+    _, _, proj = _decoder_inputs(layer, 2, 48, 101)
+    proj = proj.detach()
+    rng = np.random.default_rng(4)
+    if mask_kind == "ones":
+        mask = torch.ones(2, 6890, device=dev())
+    else:
+        mask = t(rng.choice([0.5, 1.0, 3.0, 150.0, 208.0, 209.0, 500.0, 2000.0], size=(2, 6890)))
+    pg = proj.clone().requires_grad_(True)
+    seg = projects_to_seg([pg, mask], W)
+    ids, off = part_tables[1]
+    want = o.projects_to_seg(proj.cpu().numpy().astype(np.float64), mask.cpu().numpy().astype(np.float64), W, ids, off)
+    got = seg.detach().cpu().numpy()
+    assert got.shape == (2, W, W, 32)
+    assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
+    g = rng.normal(0, 1, got.shape)
+    (seg * t(g)).sum().backward()
+    po = torch.tensor(proj.cpu().numpy(), dtype=torch.float64, requires_grad=True)
+    mo = torch.tensor(mask.cpu().numpy(), dtype=torch.float64)
+    (to.projects_to_seg(po, mo, W, ids, off) * torch.tensor(g)).sum().backward()
+    grad_close(pg.grad.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(seg, %s mask, W=50)" % mask_kind)
+
+
+def test_silhouette_odd_width_and_outliers(layer):
+    """W = 50 and vertices far outside the cell window (outlier list) in the pruned silhouette."""
+    from ilps_amd.keras_smpl.projects_to_silhouette import projects_to_silhouette
+    from oracle import np_oracle as o
+    W = 50
+    _, _, proj = _decoder_inputs(layer, 2, 48, 103)
+    proj = proj.detach().clone()
+    proj[0, :500, 0] -= 200.0                      # 500 vertices far left of the window
+    proj[1, :, 1] += 40.0                          # mesh 1 mostly below the image
+    got = projects_to_silhouette(proj, W).cpu().numpy()
+    want = o.projects_to_silhouette(proj.cpu().numpy().astype(np.float64), W)
+    assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
+    far = proj.clone()
+    far[..., :2] += 1000.0                         # everything is an outlier
+    got2 = projects_to_silhouette(far, W).cpu().numpy()
+    want2 = o.projects_to_silhouette(far.cpu().numpy().astype(np.float64), W)
+    assert np.all(np.abs(got2 - want2) <= SEG_RTOL * np.abs(want2) + SEG_ATOL)
