@@ -175,7 +175,9 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
   }
 }
 
-__global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
+constexpr int PBW = 256;   // pose backward: threads per block (one mesh)
+
+__global__ __launch_bounds__(PBW) void pose_bwd_kernel(
     const float *__restrict__ x, int x_stride, int num_cam, int B,
     const float *__restrict__ J_dirs, const int *__restrict__ parents,
     const float *__restrict__ Rs_in, const float *__restrict__ J_in, const float *__restrict__ A_in,
@@ -185,65 +187,46 @@ __global__ __launch_bounds__(MPB * 64) void pose_bwd_kernel(
     // (ns,nmt,32,224) of the blend GEMM here, in fixed order, instead of in two more launches
     const float *__restrict__ skin_part, int nblk, const float *__restrict__ blend_part, int ns, int nmt,
     int want_dcam) {
-  __shared__ PoseLds lds[MPB];
-  __shared__ float sJd[720];           // J_dirs, shared by the block's meshes (the d beta loop walks all of it)
-  for (int e = threadIdx.x; e < 720; e += MPB * 64) sJd[e] = J_dirs[e];
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blockIdx.x * MPB + wave;
-  const bool live = n < B;
-  PoseLds &L = lds[wave];
-  const size_t nn = live ? n : 0;
-
-  if (live) {
-    for (int e = lane; e < 216; e += 64) L.Rs[e / 9][e % 9] = Rs_in[nn * 216 + e];
-    for (int e = lane; e < 72; e += 64) L.J[e / 3][e % 3] = J_in[nn * 72 + e];
-    for (int e = lane; e < 288; e += 64) L.G[e / 12][e % 12] = A_in[nn * 288 + e];  // G.R = A.R
-    if (dA) {
-      for (int e = lane; e < 288; e += 64) L.dA[e / 12][e % 12] = dA[nn * 288 + e];
-      for (int e = lane; e < 220; e += 64) L.dcoef[e] = dcoef[nn * SMPLR_KPAD + e];
-      if (lane < 4) L.dcam[lane] = dcam ? dcam[nn * 4 + lane] : 0.0f;
-    } else {
-      // all of a lane's entries accumulate side by side so that one memory round trip serves
-      // 5 (4) x 9 loads instead of 9: the partials were written by the previous kernels and come
-      // from L2/HBM at ~1 us per dependent trip
-      {
-        const float *p = skin_part + (nn * nblk) * 292;
-        int off[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) off[j] = min(lane + 64 * j, 291);   // clamped: loads stay unconditional
-        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 9
-        for (int b = 0; b < nblk; ++b) {
-#pragma unroll
-          for (int j = 0; j < 5; ++j) acc[j] += p[(size_t)b * 292 + off[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const int e = lane + 64 * j;
-          if (e < 288) L.dA[e / 12][e % 12] = acc[j];
-          else if (e < 292) L.dcam[e - 288] = want_dcam ? acc[j] : 0.0f;
-        }
-      }
-      {
+  // One mesh per 256-thread block: all four waves stage the inputs and sum the producers' partials
+  // (512 entries, two per thread, their 27 / 54 loads all in flight together: ~3 memory round trips);
+  // then wave 0 alone walks the chain.
+  __shared__ PoseLds lds1;
+  __shared__ float sJd[720];           // J_dirs (the d beta loop walks all of it)
+  PoseLds &L = lds1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.x;
+  const bool live = true;
+  const size_t nn = n;
+  for (int e = tid; e < 720; e += PBW) sJd[e] = J_dirs[e];
+  for (int e = tid; e < 216; e += PBW) L.Rs[e / 9][e % 9] = Rs_in[nn * 216 + e];
+  for (int e = tid; e < 72; e += PBW) L.J[e / 3][e % 3] = J_in[nn * 72 + e];
+  for (int e = tid; e < 288; e += PBW) L.G[e / 12][e % 12] = A_in[nn * 288 + e];  // G.R = A.R
+  if (dA) {
+    for (int e = tid; e < 288; e += PBW) L.dA[e / 12][e % 12] = dA[nn * 288 + e];
+    for (int e = tid; e < 220; e += PBW) L.dcoef[e] = dcoef[nn * SMPLR_KPAD + e];
+    if (tid < 4) L.dcam[tid] = dcam ? dcam[nn * 4 + tid] : 0.0f;
+  } else {
+    for (int e = tid; e < 512; e += PBW) {
+      if (e < 292) {                                     // skinning partials (B, nblk, 292)
+        const float *p = skin_part + (nn * nblk) * 292 + e;
+        float acc = 0.0f;
+#pragma unroll 27
+        for (int b = 0; b < nblk; ++b) acc += p[(size_t)b * 292];
+        if (e < 288) L.dA[e / 12][e % 12] = acc;
+        else L.dcam[e - 288] = want_dcam ? acc : 0.0f;
+      } else if (e - 292 < 220) {                        // blend split-K partials (ns, nmt, 32, 224)
         const size_t mt = nn >> 5, r = nn & 31;
-        const float *p = blend_part + (mt * 32 + r) * 224;
+        const float *p = blend_part + (mt * 32 + r) * 224 + (e - 292);
         const size_t stride = (size_t)nmt * 32 * 224;
-        int off[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) off[j] = min(lane + 64 * j, 223);   // row stride is 224: always valid
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 9
-        for (int s = 0; s < ns; ++s) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] += p[s * stride + off[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (lane + 64 * j < 220) L.dcoef[lane + 64 * j] = acc[j];
+        float acc = 0.0f;
+#pragma unroll 27
+        for (int s = 0; s < ns; ++s) acc += p[s * stride];
+        L.dcoef[e - 292] = acc;
       }
     }
   }
+  __syncthreads();
+  if (tid >= 64) return;                                 // the rest is one wavefront's work
   wave_sync();
   if (live && lane < 24) {
     const int i = lane;
@@ -342,7 +325,7 @@ int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B, const float
                 "smplr_pose_bwd: bad sizes B=%d num_cam=%d x_stride=%d", B, num_cam, x_stride);
   if (B == 0) return 0;
   SMPLR_REQUIRE(x && J_dirs && parents && Rs && J && A && dcoef && dA && dx, "smplr_pose_bwd: null pointer");
-  hipLaunchKernelGGL(pose_bwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
+  hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(PBW), 0, as_stream(stream),
                      x, x_stride, num_cam, B, J_dirs, parents, Rs, J, A, dcoef, dA, dJ_transformed, dcam, dx,
                      (const float *)nullptr, 0, (const float *)nullptr, 0, 0, 0);
   SMPLR_LAUNCH_CHECK("smplr_pose_bwd");
@@ -385,7 +368,7 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_tran
   rc = launch_blend_bwd_partials(dv_posed, blend_t, B, 3 * V, blend_part, st);
   if (rc) return rc;
   const BlendBwdGeom g = blend_bwd_geom(B, 3 * V);
-  hipLaunchKernelGGL(pose_bwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, st, x, x_stride, num_cam, B,
+  hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(PBW), 0, st, x, x_stride, num_cam, B,
                      J_dirs, parents, Rs, J, A, (const float *)nullptr, (const float *)nullptr, dJ_transformed,
                      (const float *)nullptr, dx, skin_part, skin_bwd_nblk(V), blend_part, g.nslices, g.nmt,
                      dproj ? 1 : 0);
