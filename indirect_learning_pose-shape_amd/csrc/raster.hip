@@ -231,6 +231,7 @@ __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sq
 constexpr int HC = 8;     // channels per wave (channel group)
 constexpr int TLD = 9;    // tile row stride
 constexpr int NG = 4;     // channel groups = waves per 64-pixel group
+constexpr int NREC = 1024;  // records of a mesh's global list that fit the block's LDS copy (16 KB)
 
 // One vertex against this lane's pixel: strict '<' keeps the first arg-min in list order.
 #define SMPLR_PAIR(rec, slot)                                   \
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   __shared__ float sS[NG * RT * TLD];
   __shared__ short sA[NG * RT * TLD];
   __shared__ float sSum[NG][RT];
+  __shared__ float4 sR[NREC];
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
   const int bid = blockIdx.x;
@@ -302,6 +304,14 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   const int l0 = lstart[(size_t)n * (npix + 1) + qc], l1 = lstart[(size_t)n * (npix + 1) + qc + 1];
   const uint2 *lrecn = lrec + (size_t)n * K;
   const int lbase = goffn[P];
+  // the mesh's global record list (typically ~600 records) is copied to LDS once per block and read
+  // by its 16 waves with broadcast ds_read_b128 (in-order, counted waits); longer lists use the
+  // scalar-load path below.  Both evaluate the same fp32 expressions.
+  const bool in_lds = lbase <= NREC;                     // block-uniform
+  if (in_lds) {
+    for (int i2 = tid; i2 < lbase; i2 += RT * NG) sR[i2] = Gn[i2];
+    __syncthreads();
+  }
   float *myS = &sS[(g * RT + pt) * TLD];
   short *myA = &sA[(g * RT + pt) * TLD];
   const int ch0 = g * HC;
@@ -318,7 +328,20 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
       nxt = goffn[opaque((p + 2) < P ? (p + 2) : P)];           // prefetch the next part's end
       float best = INFINITY;
       int bslot = -1;
-      if (beg < end) {
+      if (in_lds) {
+        if (beg < end) {
+          float4 r0 = sR[beg], r1 = sR[beg + 1], r2 = sR[beg + 2], r3 = sR[beg + 3];
+          for (int k = beg; k < end; k += GP) {
+            const int kn = (k + GP < end) ? k + GP : k;         // next group in flight during this one
+            const float4 n0 = sR[kn], n1 = sR[kn + 1], n2 = sR[kn + 2], n3 = sR[kn + 3];
+            SMPLR_PAIR(r0, k)
+            SMPLR_PAIR(r1, k + 1)
+            SMPLR_PAIR(r2, k + 2)
+            SMPLR_PAIR(r3, k + 3)
+            r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+          }
+        }
+      } else if (beg < end) {
         // two record groups in flight: group k+4 is being fetched while group k is evaluated
         f32x16s ga, gb;
         sload_group(ga, Gn + beg);
