@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import ilps_amd  # noqa: E402,F401
-from ilps_amd import ops  # noqa: E402
+from ilps_amd import ops, _lib  # noqa: E402
 from ilps_amd.smpl_model import synthetic_smpl_model, mean86, load_part_tables  # noqa: E402
 
 # algorithmic work of the segmentation raster forward per mesh at W=48:
@@ -279,6 +279,28 @@ def main():
             t_smpl = event_time_ms(smpl_only, 30, torch.cuda.current_stream())
             line["aux"] = {"batch_smpl_fwd_bwd_B256": {"meshes_per_s": round(256 / (t_smpl * 1e-3), 1),
                                                        "ms_per_step": round(t_smpl, 4), "launch": "eager"}}
+            # loss head: softmax + focal loss on the (B,W,W,32) scores, HBM-bound.
+            # algorithmic bytes: fwd = scores 128 + label 4 + loss 4 B/pixel; bwd = 128 + 4 + 4 + 128 B/pixel
+            seg_s = torch.rand(B, W, W, 32, device=dev)
+            lab = torch.randint(0, 32, (B, W * W), device=dev, dtype=torch.int32)
+            cw = torch.ones(32, device=dev)
+            dl = torch.full((B, W * W), 1.0 / (B * W * W), device=dev)
+            lossb, dsc = torch.empty(B, W * W, device=dev), torch.empty_like(seg_s)
+            lib, P_, st_ = _lib.load(), _lib.ptr, _lib.stream
+            f_fwd = lambda: lib.smplr_focal_fwd(P_(seg_s), P_(lab), None, P_(cw), 2.0, B * W * W, 32, P_(lossb),
+                                                None, st_())
+            f_bwd = lambda: lib.smplr_focal_bwd(P_(seg_s), P_(lab), None, P_(cw), 2.0, P_(dl), B * W * W, 32,
+                                                P_(dsc), st_())
+            for _ in range(3):
+                f_fwd(); f_bwd()
+            tf_ms = event_time_ms(f_fwd, 50, torch.cuda.current_stream())
+            tb_ms = event_time_ms(f_bwd, 50, torch.cuda.current_stream())
+            npx = B * W * W
+            line["aux"]["loss_head_softmax_focal"] = {
+                "fwd_us": round(tf_ms * 1e3, 2), "bwd_us": round(tb_ms * 1e3, 2),
+                "fwd_GBps": round(npx * 136 / (tf_ms * 1e-3) / 1e9, 1),
+                "bwd_GBps": round(npx * 264 / (tb_ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000,
+                "note": "latency-bound at B=128 (37.7 MB tensor); bytes = algorithmic, per SURVEY 8(f) next-2"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(model, W)

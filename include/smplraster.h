@@ -167,6 +167,24 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
 int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg,
                    const float *proj, int B, int VP, int W, float *dproj, void *stream);
 
+/* ---- loss head: model.py:119-120 + focal_loss.py:10-46 ----------- */
+/* Reshape(W*W, C) + softmax + categorical_focal_loss fused: logits (npix, C) are the raw
+ * rasteriser scores (seg: C = 32, silhouette: C = 2), loss (npix) is the per-pixel value the Keras
+ * loss function returns:  sum_c y_c w_c (1 - p_c)^gamma (-log p_c),  p = clip(softmax, 1e-7, 1-1e-7).
+ * Targets: EITHER labels (npix) int32 class ids (y = one-hot; an id outside [0,C) gives y = 0)
+ * OR y_true (npix, C) fp32 (the reference's one-hot format, train.py:18-31); the other is NULL.
+ * class_w (C) or NULL (= focal_loss.py:22-40's weights when weight_classes, else ones).
+ * gamma = 0, class_w = NULL is Keras' categorical_crossentropy on the softmax output
+ * (train_stage2_silhouette.py:85-86,226-229).  probs (npix, C) optional (NULL): the softmax,
+ * i.e. the 'segs' model output.  bwd: dlogits = dloss[pix] * dL/dlogits, softmax recomputed;
+ * the clip passes gradient only where eps <= softmax <= 1-eps (tf.clip_by_value).             */
+int smplr_focal_fwd(const float *logits, const int32_t *labels, const float *y_true,
+                    const float *class_w, float gamma, long long npix, int C,
+                    float *loss, float *probs, void *stream);
+int smplr_focal_bwd(const float *logits, const int32_t *labels, const float *y_true,
+                    const float *class_w, float gamma, const float *dloss, long long npix, int C,
+                    float *dlogits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

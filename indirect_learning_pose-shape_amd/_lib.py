@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 import torch
 
@@ -46,6 +46,8 @@ SIGNATURES = {
     "smplr_silh_workspace": (c_size_t, [I, I, I]),
     "smplr_silh_fwd": (c_int, [P, I, I, I, P, P, P, P]),
     "smplr_silh_bwd": (c_int, [P, P, P, P, I, I, I, P, P]),
+    "smplr_focal_fwd": (c_int, [P, P, P, P, c_float, c_longlong, I, P, P, P]),
+    "smplr_focal_bwd": (c_int, [P, P, P, P, c_float, P, c_longlong, I, P, P]),
 }
 
 _lib = None

@@ -34,6 +34,18 @@ def categorical_focal_loss(gamma=2.0, weight_classes=False):
     return categorical_focal_loss_fixed
 
 
+def softmax_focal_loss(gamma=2.0, weight_classes=False):
+    """The fused loss head on the HIP path: `loss(y_true, scores)` with RAW rasteriser scores
+    (N,W,W,C) or (N,W*W,C) -- Reshape + softmax (model.py:119-120) and the focal loss above in one
+    kernel forward, one backward (smplr_focal_fwd/bwd).  y_true: integer class map or one-hot.
+    gamma=0, weight_classes=False is Keras' categorical_crossentropy (the silhouette head)."""
+    def loss(y_true, scores):
+        from . import ops
+        w = class_weights(scores.device)[: scores.shape[-1]].contiguous() if weight_classes else None
+        return ops.SoftmaxFocalFn.apply(scores, y_true, w, float(gamma))
+    return loss
+
+
 def classlab(labels, num_classes=32):
     """train.py:18-31 (`classlab`): (..., H, W[,1]) integer label image -> one-hot (..., H, W, C).
     The reference does this with a Python double loop per image; here it is one scatter on device."""

@@ -342,6 +342,66 @@ class SilhRasterFn(torch.autograd.Function):
         return _silh_bwd(dsilh, silh, arg, proj, ctx.W), None
 
 
+def _focal_targets(target, npix, C):
+    """labels (int class ids, npix) -> (labels, None); dense y_true (npix, C) -> (None, y_true)."""
+    if target.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8):
+        if target.numel() != npix:
+            raise RuntimeError("labels hold %d entries for %d pixels" % (target.numel(), npix))
+        return require_cuda(target.to(torch.int32), "labels", torch.int32), None
+    if target.numel() != npix * C:
+        raise RuntimeError("y_true holds %d entries, expected %d x %d" % (target.numel(), npix, C))
+    return None, require_cuda(target, "y_true")
+
+
+class SoftmaxFocalFn(torch.autograd.Function):
+    """Raw scores (..., C) + targets -> per-pixel focal loss (N, W*W)  (model.py:119-120 +
+    focal_loss.py:10-46; gamma = 0 without weights = the silhouette head's cross-entropy).
+    Targets are data: no gradient.  The softmax is recomputed in backward, not stored."""
+
+    @staticmethod
+    def forward(ctx, scores, target, class_w, gamma: float):
+        scores = require_cuda(scores, "scores")
+        C = scores.shape[-1]
+        N = scores.shape[0]
+        npix = scores.numel() // C if C else 0
+        labels, y_true = _focal_targets(target, npix, C)
+        if class_w is not None:
+            class_w = require_cuda(class_w, "class_w")
+            if class_w.numel() != C:
+                raise RuntimeError("class_w needs %d entries" % C)
+        loss = _empty((N, npix // N if N else 0), scores)
+        check(_lib.load().smplr_focal_fwd(ptr(scores), ptr(labels), ptr(y_true), ptr(class_w), float(gamma),
+                                          npix, C, ptr(loss), None, stream()), "smplr_focal_fwd")
+        ctx.gamma, ctx.npix, ctx.C = float(gamma), npix, C
+        ctx.save_for_backward(scores, labels if labels is not None else y_true, class_w)
+        ctx.is_labels = labels is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        scores, tgt, class_w = ctx.saved_tensors
+        dloss = require_cuda(dloss, "dloss")
+        labels, y_true = (tgt, None) if ctx.is_labels else (None, tgt)
+        dscores = torch.empty_like(scores)
+        check(_lib.load().smplr_focal_bwd(ptr(scores), ptr(labels), ptr(y_true), ptr(class_w), ctx.gamma,
+                                          ptr(dloss), ctx.npix, ctx.C, ptr(dscores), stream()), "smplr_focal_bwd")
+        return dscores, None, None, None
+
+
+def softmax_probs(scores):
+    """Softmax over the last axis through the loss kernel's forward (the 'segs' model output,
+    model.py:119-120); no autograd (use torch.softmax where a gradient through probs is needed)."""
+    scores = require_cuda(scores, "scores")
+    C = scores.shape[-1]
+    npix = scores.numel() // C
+    labels = torch.zeros(npix, dtype=torch.int32, device=scores.device)
+    loss = _empty((npix,), scores)
+    probs = torch.empty_like(scores)
+    check(_lib.load().smplr_focal_fwd(ptr(scores), ptr(labels), None, None, 0.0, npix, C, ptr(loss), ptr(probs),
+                                      stream()), "smplr_focal_fwd")
+    return probs.reshape(scores.shape[0], -1, C)
+
+
 _side_streams = {}
 
 

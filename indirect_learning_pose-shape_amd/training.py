@@ -14,7 +14,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .decoder import SMPLDecoder
-from .focal_loss import categorical_focal_loss
+from .focal_loss import softmax_focal_loss
 from .model import SMPLRegressor
 
 
@@ -35,7 +35,8 @@ class SegTrainer:
             self.net = nn.parallel.DistributedDataParallel(
                 self.smpl_model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True)
-        self.loss_fn = categorical_focal_loss(gamma, weight_classes)
+        self.loss_fn = softmax_focal_loss(gamma, weight_classes)      # softmax + focal loss, one HIP kernel
+        self.silh_loss_fn = softmax_focal_loss(0.0, False)            # softmax + categorical CE
         self.opt = torch.optim.Adam(self.smpl_model.parameters(), lr=lr)       # train.py:179
 
     def step(self, images, labels, silh_labels=None):
@@ -44,13 +45,9 @@ class SegTrainer:
         self.opt.zero_grad(set_to_none=True)
         param = self.net(images)
         out = self.decoder(param)
-        seg = out["seg"]
-        probs = torch.softmax(seg.reshape(seg.shape[0], -1, seg.shape[-1]), dim=-1)   # model.py:119-120
-        loss = self.loss_fn(labels, probs).mean()
-        if self.with_silhouette and silh_labels is not None:      # stage 2: categorical cross-entropy
-            s = out["silhouette"].reshape(seg.shape[0], -1, 2).clamp(1e-7, 1.0)
-            s = s / s.sum(-1, keepdim=True)                         # Keras rescales y_pred to sum 1
-            loss = loss + (-(silh_labels * torch.log(s)).sum(-1)).mean()
+        loss = self.loss_fn(labels, out["seg"]).mean()             # model.py:119-120 + focal_loss.py
+        if self.with_silhouette and silh_labels is not None:      # train_stage2_silhouette.py:85-86,226-229
+            loss = loss + self.silh_loss_fn(silh_labels, out["silhouette"]).mean()
         loss.backward()
         self.opt.step()
         return loss.detach()

@@ -268,3 +268,37 @@ def concat_mean_param(img_features, img_wh, mean_pose, mean_shape):
     f = np.asarray(img_features, F)
     mean = np.tile(_mean_row(img_wh, mean_pose, mean_shape), (f.shape[0], 1))
     return np.concatenate([f, mean], axis=1)
+
+
+# --------------------------------------------------------------------------- loss head
+FOCAL_CLASS_WEIGHTS = np.ones(32, F)                     # `focal_loss.py:22-40`
+FOCAL_CLASS_WEIGHTS[0] = 0.3
+FOCAL_CLASS_WEIGHTS[[1, 2, 3, 4, 10, 12, 14, 15, 16, 17, 23, 25]] = 2.0
+K_EPSILON = 1e-7                                         # keras.backend.epsilon()
+
+
+def softmax_last(scores):
+    """`model.py:119-120`: Reshape((W*W, C)) + Activation('softmax') over the class axis."""
+    s = np.asarray(scores, F)
+    s = s.reshape(s.shape[0], -1, s.shape[-1])
+    e = np.exp(s - s.max(axis=-1, keepdims=True))
+    return e / e.sum(axis=-1, keepdims=True)
+
+
+def categorical_focal_loss(y_true, y_pred, gamma=2.0, weight_classes=False):
+    """`focal_loss.py:10-46`: y_true, y_pred (N, W*W, C) -> per-pixel loss (N, W*W)."""
+    y_true, y_pred = np.asarray(y_true, F), np.asarray(y_pred, F)
+    p = np.clip(y_pred, K_EPSILON, 1.0 - K_EPSILON)               # :17
+    ce = -y_true * np.log(p)                                       # :18
+    if weight_classes:
+        ce = ce * FOCAL_CLASS_WEIGHTS[: p.shape[-1]]               # :20-41
+    return (np.power(1.0 - p, gamma) * ce).sum(axis=2)             # :43-44
+
+
+def categorical_crossentropy(y_true, y_pred):
+    """Keras 2.1 `categorical_crossentropy` on probabilities (the silhouette head's loss,
+    `train_stage2_silhouette.py:226-229`): rescale to row sum 1, clip, -sum(y log p)."""
+    y_true, y_pred = np.asarray(y_true, F), np.asarray(y_pred, F)
+    p = y_pred / y_pred.sum(axis=-1, keepdims=True)
+    p = np.clip(p, K_EPSILON, 1.0 - K_EPSILON)
+    return -(y_true * np.log(p)).sum(axis=-1)

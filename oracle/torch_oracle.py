@@ -150,3 +150,15 @@ def decoder_forward(smpl: TorchSMPL, x, mask_fn, img_wh, part_ids, part_off,
     mask = mask_fn(proj.detach())
     seg = projects_to_seg(proj, mask, img_wh, part_ids, part_off, vertex_sampling)
     return verts, proj, mask, seg
+
+
+# --------------------------------------------------------------------------- loss head
+def softmax_focal_loss(scores, y_true, gamma=2.0, class_w=None):
+    """`model.py:119-120` + `focal_loss.py:10-46`, differentiable: raw scores (N, W, W, C) or
+    (N, W*W, C), y_true one-hot/soft (N, W*W, C) -> per-pixel loss (N, W*W)."""
+    s = scores.reshape(scores.shape[0], -1, scores.shape[-1])
+    p = torch.softmax(s, dim=-1).clamp(1e-7, 1.0 - 1e-7)           # focal_loss.py:17
+    ce = -y_true * torch.log(p)                                    # :18
+    if class_w is not None:
+        ce = ce * class_w                                          # :41
+    return ((1.0 - p) ** gamma * ce).sum(dim=2)                    # :43-44

@@ -443,3 +443,86 @@ def test_silhouette_odd_width_and_outliers(layer):
     got2 = projects_to_silhouette(far, W).cpu().numpy()
     want2 = o.projects_to_silhouette(far.cpu().numpy().astype(np.float64), W)
     assert np.all(np.abs(got2 - want2) <= SEG_RTOL * np.abs(want2) + SEG_ATOL)
+
+
+# ----------------------------------------------------------------------------------- loss head
+LOSS_RTOL = 1e-4      # fp32 softmax + log against float64
+
+
+def _loss_case(N, W, C, seed, confident=False):
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(0, 1, (N, W, W, C)).astype(np.float32)       # rasteriser scores live in [0,1]
+    if confident:                                                # logits that saturate the clip
+        s = (s * 40.0).astype(np.float32)
+    lab = rng.integers(0, C, (N, W * W))
+    return s, lab
+
+
+@pytest.mark.parametrize("C,gamma,weighted,dense", [(32, 2.0, True, False), (32, 2.0, False, True),
+                                                    (32, 1.5, True, True), (2, 0.0, False, True),
+                                                    (2, 0.0, False, False), (32, 0.0, False, False)])
+def test_focal_loss_forward_backward(C, gamma, weighted, dense):
+    from oracle import np_oracle as o
+    from oracle import torch_oracle as to
+    from ilps_amd import ops
+    N, W = 3, 17                                                  # ragged: 867 pixels, not a block multiple
+    s, lab = _loss_case(N, W, C, seed=C + int(gamma * 10))
+    y = np.eye(C)[lab]
+    if dense and C == 32:
+        y = y * 0.9 + 0.1 / C                                     # soft labels exercise every class term
+    w64 = o.FOCAL_CLASS_WEIGHTS[:C] if weighted else None
+    sd = t(s).requires_grad_(True)
+    tgt = t(y) if dense else t(lab, torch.int64)
+    loss = ops.SoftmaxFocalFn.apply(sd, tgt, t(w64) if weighted else None, gamma)
+    cot = np.random.default_rng(1).normal(0, 1, (N, W * W))
+    (loss * t(cot)).sum().backward()
+    torch.cuda.synchronize()
+    s64 = torch.tensor(s, dtype=torch.float64, requires_grad=True)
+    ref = to.softmax_focal_loss(s64, torch.tensor(y), gamma, torch.tensor(w64) if weighted else None)
+    (ref * torch.tensor(cot)).sum().backward()
+    want = ref.detach().numpy()
+    assert np.allclose(want, o.categorical_focal_loss(y, o.softmax_last(s), gamma, weighted), rtol=1e-10)
+    got = loss.detach().cpu().numpy()
+    assert got.shape == (N, W * W)
+    assert np.all(np.abs(got - want) <= LOSS_RTOL * np.abs(want) + 1e-7)
+    grad_close(sd.grad.cpu().numpy(), s64.grad.numpy(), rtol=2e-4, name="dscores")
+
+
+def test_focal_loss_clip_gate_and_probs():
+    """Saturated pixels: loss clipped at eps / 1-eps, gradient exactly 0 there (tf.clip_by_value);
+    probs output = softmax."""
+    from oracle import np_oracle as o
+    from ilps_amd import ops
+    s, lab = _loss_case(2, 8, 32, seed=9, confident=True)
+    s[0, 0, 0, :] = 0.0
+    s[0, 0, 0, 3] = 120.0
+    lab[0, 0] = 3                                                 # confidently right -> p clipped to 1-eps
+    s[0, 0, 1, :] = 0.0
+    s[0, 0, 1, 4] = 120.0
+    lab[0, 1] = 9                                                 # confidently wrong -> p clipped to eps
+    sd = t(s).requires_grad_(True)
+    loss = ops.SoftmaxFocalFn.apply(sd, t(lab, torch.int64), None, 2.0)
+    loss.sum().backward()
+    y = np.eye(32)[lab]
+    want = o.categorical_focal_loss(y, o.softmax_last(s), 2.0, False)
+    got = loss.detach().cpu().numpy()
+    assert np.all(np.abs(got - want) <= 1e-3 * np.abs(want) + 1e-12)
+    g = sd.grad.cpu().numpy()
+    assert np.all(g[0, 0, 0] == 0.0) and np.all(g[0, 0, 1] == 0.0)
+    assert np.isfinite(g).all()
+    probs = ops.softmax_probs(t(s)).cpu().numpy()
+    assert np.allclose(probs, o.softmax_last(s), rtol=1e-5, atol=1e-9)
+    assert np.allclose(probs.sum(-1), 1.0, atol=1e-6)
+
+
+def test_focal_loss_argument_errors():
+    from ilps_amd import ops
+    s = torch.zeros(2, 4, 4, 7, device=dev())
+    with pytest.raises(RuntimeError, match="32 .parts. or 2"):
+        ops.SoftmaxFocalFn.apply(s, torch.zeros(2, 16, dtype=torch.int64, device=dev()), None, 2.0)
+    s = torch.zeros(2, 4, 4, 32, device=dev())
+    with pytest.raises(RuntimeError, match="labels hold"):
+        ops.SoftmaxFocalFn.apply(s, torch.zeros(2, 15, dtype=torch.int64, device=dev()), None, 2.0)
+    empty = ops.SoftmaxFocalFn.apply(torch.zeros(0, 4, 4, 32, device=dev()),
+                                     torch.zeros(0, 16, dtype=torch.int64, device=dev()), None, 2.0)
+    assert empty.shape == (0, 0) or empty.numel() == 0

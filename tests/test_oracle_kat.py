@@ -197,3 +197,42 @@ def test_conditioning():
     assert np.all(b[0, 4:7] == 0) and np.isclose(b[0, 76], 0.20560974, atol=1e-7)
     c = o.concat_mean_param(np.ones((2, 2048)), 48, pose, shape)
     assert c.shape == (2, 2134) and np.array_equal(c[:, 2048:], o.load_mean_set_cam_params(z, 48, pose, shape))
+
+
+# ----------------------------------------------------------------------------------- loss head
+def test_focal_loss_uniform_scores_kat():
+    """Equal scores => softmax = 1/C; loss = w_t (1 - 1/C)^gamma log C at the labelled class."""
+    N, W, C = 2, 3, 32
+    y = np.zeros((N, W * W, C))
+    lab = np.arange(N * W * W).reshape(N, W * W) % C
+    np.put_along_axis(y, lab[..., None], 1.0, axis=2)
+    p = o.softmax_last(np.full((N, W, W, C), 0.37))
+    assert np.allclose(p, 1.0 / C)
+    got = o.categorical_focal_loss(y, p, 2.0, True)
+    want = o.FOCAL_CLASS_WEIGHTS[lab] * (1 - 1 / C) ** 2 * np.log(C)
+    assert np.allclose(got, want, rtol=1e-12)
+    assert np.allclose(o.categorical_focal_loss(y, p, 0.0, False), np.log(C))     # plain CE
+    assert np.allclose(o.categorical_crossentropy(y, p), np.log(C))
+
+
+def test_focal_loss_clip_kat():
+    """A confident wrong pixel is clipped at eps: loss = (1-eps)^2 * -log(eps); a confident right
+    one at 1-eps: loss = eps^2 * -log(1-eps) ~ 1e-21."""
+    s = np.zeros((1, 1, 2, 32))
+    s[0, 0, :, 5] = 100.0
+    p = o.softmax_last(s)
+    y = np.zeros((1, 2, 32))
+    y[0, 0, 5] = 1.0      # right
+    y[0, 1, 7] = 1.0      # wrong
+    got = o.categorical_focal_loss(y, p, 2.0, False)[0]
+    assert np.isclose(got[0], 1e-14 * -np.log(1 - 1e-7), rtol=1e-6)
+    assert np.isclose(got[1], (1 - 1e-7) ** 2 * -np.log(1e-7), rtol=1e-12)
+
+
+def test_focal_torch_oracle_matches_numpy():
+    rng = np.random.default_rng(5)
+    s = rng.uniform(0, 1, (2, 4, 4, 32))
+    y = np.eye(32)[rng.integers(0, 32, (2, 16))]
+    a = o.categorical_focal_loss(y, o.softmax_last(s), 2.0, True)
+    b = to.softmax_focal_loss(torch.tensor(s), torch.tensor(y), 2.0, torch.tensor(o.FOCAL_CLASS_WEIGHTS)).numpy()
+    assert np.allclose(a, b, rtol=1e-12)
