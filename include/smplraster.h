@@ -150,6 +150,13 @@ int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W,
                   const int32_t *part_pos, const int32_t *part_off, int P, int K,
                   void *workspace, float *seg, int16_t *arg, float *rec, void *stream);
 
+/* compute_mask + projects_to_seg in one call (the model.py:113-118 pair as the fused decoder
+ * runs it): same results as smplr_visibility followed by smplr_seg_fwd, the z-buffer being built
+ * inside the binning workgroup; mask (B,VP) is an OUTPUT here.  Same workspace as smplr_seg_fwd. */
+int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int ref_compat,
+                      const int32_t *part_pos, const int32_t *part_off, int P, int K,
+                      void *workspace, float *mask, float *seg, int16_t *arg, float *rec, void *stream);
+
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:
  * NaN).  The score is recomputed from the arg-min record, so seg itself is not an input.

@@ -51,6 +51,13 @@ int launch_skin_bwd_partials(const float *dverts, const float *dproj, const floa
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
                              int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st);
 
+// Depth as an unsigned key whose order is the float order (visibility z-buffer, compute_mask.py:98-103).
+__device__ __forceinline__ unsigned int orderable(float z) {
+  z += 0.0f;  // -0 -> +0 so that equal depths compare equal (tf.argmax treats them as ties)
+  const unsigned int b = __float_as_uint(z);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -66,13 +66,12 @@ struct Slot {
   float u, v, m, x;
 };
 
-__device__ __forceinline__ Slot classify(const float *__restrict__ pj, const float *__restrict__ mk, int pos,
-                                         int W) {
+__device__ __forceinline__ Slot classify(const float *__restrict__ pj, float m, int pos, int W) {
   Slot s;
   s.pos = pos;
   s.u = pj[pos * 3];
   s.v = pj[pos * 3 + 1];
-  s.m = mk[pos];
+  s.m = m;
   s.cls = 1;
   s.pix = 0;
   s.x = 0.f;
@@ -94,19 +93,61 @@ __device__ __forceinline__ Slot classify(const float *__restrict__ pj, const flo
 // rec[n] (S = Kpad + K slots of (u, v, m^2, vertex)): [0, goff[P]) the global list, part-major,
 // padded per part; [goff[P], goff[P] + L) the local records in pixel order.  Saved for backward.
 // scratch per mesh: goff[P+1] | lstart[npix+1] | lrec[K] uint2 (x bits, part)
+// VIS = true fuses compute_mask (visibility.hip's kernel, same arithmetic) in front: the z-buffer
+// over the vgrid x vgrid grid and the per-vertex flags live in LDS after the pixel counters, the
+// mask is written out (it is an output of the decoder) and classification reads the flags.
+template <bool VIS>
 __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict__ proj,
-                                                        const float *__restrict__ mask,
+                                                        float *__restrict__ mask,
                                                         const int *__restrict__ part_pos,
                                                         const int *__restrict__ part_off, int P, int K,
                                                         int VP, int W, int S, float4 *__restrict__ G,
                                                         int *__restrict__ goff, int *__restrict__ lstart,
-                                                        uint2 *__restrict__ lrec) {
-  extern __shared__ int s_cnt[];   // npix
+                                                        uint2 *__restrict__ lrec, int vgrid, int ref_compat) {
+  extern __shared__ int s_cnt[];   // npix (+ VIS: z-buffer keys, visible flags)
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
+  __shared__ int s_any_empty;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int npix = W * W;
   const float *pj = proj + (size_t)n * VP * 3;
-  const float *mk = mask + (size_t)n * VP;
+  float *mk = mask + (size_t)n * VP;
+  unsigned int *vis = nullptr;
+  if (VIS) {
+    unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(s_cnt + ((npix + 1) & ~1));
+    const int cells = vgrid * vgrid, words = (VP + 31) / 32;
+    vis = reinterpret_cast<unsigned int *>(zbuf + cells);
+    for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
+    for (int i = tid; i < words; i += BIN_T) vis[i] = 0u;
+    if (tid == 0) s_any_empty = 0;
+    __syncthreads();
+    const float fG = (float)vgrid;
+    for (int v = tid; v < VP; v += BIN_T) {
+      const float pu = rintf(pj[v * 3 + 0]);   // round half to even, like tf.round (compute_mask.py:22)
+      const float pv = rintf(pj[v * 3 + 1]);
+      if (pu >= 0.0f && pu < fG && pv >= 0.0f && pv < fG) {
+        const int cell = (int)pv * vgrid + (int)pu;
+        const unsigned long long key = ((unsigned long long)orderable(pj[v * 3 + 2]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)v);
+        atomicMax(&zbuf[cell], key);
+      }
+    }
+    __syncthreads();
+    int empty = 0;
+    for (int i = tid; i < cells; i += BIN_T) {
+      const unsigned long long key = zbuf[i];
+      if (key == 0ull) {
+        empty = 1;
+      } else {
+        const unsigned int v = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+        atomicOr(&vis[v >> 5], 1u << (v & 31));
+      }
+    }
+    if (empty) s_any_empty = 1;   // benign same-value race
+    __syncthreads();
+    if (tid == 0 && s_any_empty && ref_compat && VP > 1) atomicOr(&vis[0], 2u);   // vertex 1 (:99)
+    __syncthreads();
+    for (int v = tid; v < VP; v += BIN_T) mk[v] = ((vis[v >> 5] >> (v & 31)) & 1u) ? 1.0f : 500.0f;
+  }
   float4 *Gn = G + (size_t)n * S;
   int *goffn = goff + (size_t)n * (P + 1);
   int *lstartn = lstart + (size_t)n * (npix + 1);
@@ -125,7 +166,11 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   for (int j = 0; j < IPT_MAX; ++j) {
     const int k = k0 + j;
     sl[j].cls = 0;
-    if (j < ipt && k < k1) sl[j] = classify(pj, mk, part_pos[k], W);
+    if (j < ipt && k < k1) {
+      const int pos = part_pos[k];
+      const float m = VIS ? (((vis[pos >> 5] >> (pos & 31)) & 1u) ? 1.0f : 500.0f) : mk[pos];
+      sl[j] = classify(pj, m, pos, W);
+    }
     if (sl[j].cls == 1) ++gcnt;
     else if (sl[j].cls == 2) atomicAdd(&s_cnt[sl[j].pix], 1);
   }
@@ -427,21 +472,19 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
 // one 16-B gather; the score is recomputed from it (seg is not re-read).
 // Per-block slot sums go to a partial buffer with plain coalesced stores and are summed in fixed
 // order by seg_bwd_merge_kernel, which scatters each slot to its vertex (one slot per vertex, so
-// plain stores).  Slots >= SB_SLOTS (only meshes with > 4096 records) use global atomics.
+// plain stores; the blocks of a mesh zero its dproj rows first, so there is no memset and no
+// global atomic).  A mesh with more than SB_SLOTS records (only when most vertices are marked
+// visible) is walked once per window of SB_SLOTS slots.  Run-to-run differences are confined to
+// the order in which a block's strips reach a slot's LDS accumulator (last-ulp rounding).
 constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators
+constexpr int SB_NWIN = 5;       // slot windows the partial buffer holds: S <= 20480
 constexpr int SB_ROWS = 8;       // rows (strips) per block
 constexpr int SB_U = 4;          // pixels in flight per lane
 
-__device__ __forceinline__ void seg_flush(float *acc, const float4 *R, float *dp, int cur, float sx, float sy) {
+__device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float sy) {
   if (cur >= 0 && (sx != 0.0f || sy != 0.0f)) {
-    if (cur < SB_SLOTS) {
-      atomicAdd(&acc[cur * 2], sx);
-      atomicAdd(&acc[cur * 2 + 1], sy);
-    } else {
-      const int v = __float_as_int(R[cur].w);
-      atomicAdd(&dp[v * 3], sx);
-      atomicAdd(&dp[v * 3 + 1], sy);
-    }
+    atomicAdd(&acc[cur * 2], sx);
+    atomicAdd(&acc[cur * 2 + 1], sy);
   }
 }
 
@@ -454,66 +497,78 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
   const int n = blockIdx.y, tid = threadIdx.x;
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
-  const int nsl = nslots < SB_SLOTS ? nslots : SB_SLOTS;
-  for (int i = tid; i < nsl * 2; i += 256) acc[i] = 0.0f;
-  __syncthreads();
+  {
+    // this block's share of the mesh's dproj rows := 0 (the merge kernel then stores the sums)
+    float *dp = dproj + (size_t)n * VP * 3;
+    const int tot = VP * 3, per = (tot + gridDim.x - 1) / gridDim.x;
+    const int z0 = blockIdx.x * per, z1 = min(tot, z0 + per);
+    for (int i = z0 + tid; i < z1; i += 256) dp[i] = 0.0f;
+  }
   const int C = P + 1, npix = W * W;
-  float *dp = dproj + (size_t)n * VP * 3;
   const int ch = tid & 31, strip = tid >> 5;
   const int ro = blockIdx.x * SB_ROWS + strip;            // output (flipped) row of this strip
   const int cbeg = 0, cend = W;
-  if (ro < W) {
-    const float fr = (float)(W - 1 - ro);
-    const size_t row0 = (size_t)n * npix + (size_t)ro * W;
-    int cur = -1;
-    float sx = 0.0f, sy = 0.0f;
-    for (int c0 = cbeg; c0 < cend; c0 += SB_U) {
-      int a[SB_U];
-      float g[SB_U];
+  const float fr = (float)(W - 1 - ro);
+  const size_t row0 = (size_t)n * npix + (size_t)ro * W;
+  const int nwin = (nslots + SB_SLOTS - 1) / SB_SLOTS;    // 1 in the standard pipeline
+  for (int win = 0; win < nwin; ++win) {
+    const int base = win * SB_SLOTS;
+    const int nsl = min(nslots - base, SB_SLOTS);
+    if (win > 0) __syncthreads();
+    for (int i = tid; i < nsl * 2; i += 256) acc[i] = 0.0f;
+    __syncthreads();
+    if (ro < W) {
+      int cur = -1;
+      float sx = 0.0f, sy = 0.0f;
+      for (int c0 = cbeg; c0 < cend; c0 += SB_U) {
+        int a[SB_U];
+        float g[SB_U];
 #pragma unroll
-      for (int u = 0; u < SB_U; ++u) {
-        const int cc = (c0 + u < cend) ? c0 + u : cend - 1;
-        const size_t po = row0 + cc;
-        a[u] = arg[po * 32 + ch];
-        g[u] = dseg[po * C + min(ch, C - 1)];       // unconditional load (slots >= C are masked below)
-      }
-      float4 rv[SB_U];
+        for (int u = 0; u < SB_U; ++u) {
+          const int cc = (c0 + u < cend) ? c0 + u : cend - 1;
+          const size_t po = row0 + cc;
+          a[u] = arg[po * 32 + ch];
+          g[u] = dseg[po * C + min(ch, C - 1)];       // unconditional load (slots >= C are masked below)
+        }
+        float4 rv[SB_U];
 #pragma unroll
-      for (int u = 0; u < SB_U; ++u) {
-        const int gate = __shfl(a[u], 0, 32);     // channel-0 lane of this pixel: 1 = clip passes gradient
-        const float g0 = __shfl(g[u], 0, 32);
-        g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
-        if (!(ch >= 1 && ch < C && c0 + u < cend)) a[u] = -1;
-        rv[u] = R[a[u] >= 0 ? a[u] : 0];
-      }
+        for (int u = 0; u < SB_U; ++u) {
+          const int gate = __shfl(a[u], 0, 32);     // channel-0 lane of this pixel: 1 = clip passes gradient
+          const float g0 = __shfl(g[u], 0, 32);
+          g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
+          if (!(ch >= 1 && ch < C && c0 + u < cend)) a[u] = -1;
+          if (nwin > 1 && (a[u] < base || a[u] >= base + SB_SLOTS)) a[u] = -1;   // another window's slot
+          rv[u] = R[a[u] >= 0 ? a[u] : 0];
+        }
 #pragma unroll
-      for (int u = 0; u < SB_U; ++u) {
-        if (a[u] >= 0) {
-          const float fc = (float)(c0 + u);
-          const float du = rv[u].x - fc, dv = rv[u].y - fr;
-          const float d2 = fmaf(du, du, dv * dv);
-          const float x = fast_sqrt(d2 * rv[u].z);          // m * d, as the forward computed it
-          // d score / d(u,v) = -score * m * (p - q) / d = -score * x * (p - q) / d^2
-          const float k = -g[u] * fast_exp_neg(x) * x;
-          if (d2 > 0.0f && k != 0.0f) {
-            const float kk = k / d2;
-            if (a[u] != cur) {
-              seg_flush(acc, R, dp, cur, sx, sy);
-              cur = a[u];
-              sx = 0.0f;
-              sy = 0.0f;
+        for (int u = 0; u < SB_U; ++u) {
+          if (a[u] >= 0) {
+            const float fc = (float)(c0 + u);
+            const float du = rv[u].x - fc, dv = rv[u].y - fr;
+            const float d2 = fmaf(du, du, dv * dv);
+            const float x = fast_sqrt(d2 * rv[u].z);          // m * d, as the forward computed it
+            // d score / d(u,v) = -score * m * (p - q) / d = -score * x * (p - q) / d^2
+            const float k = -g[u] * fast_exp_neg(x) * x;
+            if (d2 > 0.0f && k != 0.0f) {
+              const float kk = k / d2;
+              if (a[u] != cur) {
+                seg_flush(acc, cur - base, sx, sy);
+                cur = a[u];
+                sx = 0.0f;
+                sy = 0.0f;
+              }
+              sx = fmaf(kk, du, sx);
+              sy = fmaf(kk, dv, sy);
             }
-            sx = fmaf(kk, du, sx);
-            sy = fmaf(kk, dv, sy);
           }
         }
       }
+      seg_flush(acc, cur - base, sx, sy);
     }
-    seg_flush(acc, R, dp, cur, sx, sy);
+    __syncthreads();
+    float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
+    for (int i = tid; i < nsl * 2; i += 256) dst[i] = acc[i];
   }
-  __syncthreads();
-  float *dst = part + ((size_t)n * gridDim.x + blockIdx.x) * (SB_SLOTS * 2);
-  for (int i = tid; i < nsl * 2; i += 256) dst[i] = acc[i];
 }
 
 __global__ __launch_bounds__(256) void seg_bwd_merge_kernel(const float *__restrict__ part,
@@ -522,23 +577,18 @@ __global__ __launch_bounds__(256) void seg_bwd_merge_kernel(const float *__restr
   const int n = blockIdx.y;
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
-  const int nsl = nslots < SB_SLOTS ? nslots : SB_SLOTS;
-  const int slot = blockIdx.x * 256 + threadIdx.x;
-  if (slot >= nsl) return;
-  const int v = __float_as_int(R[slot].w);
-  if (v < 0) return;                                       // padding sentinel
-  const float *p = part + (size_t)n * nsplit * (SB_SLOTS * 2) + slot * 2;
-  float sx = 0.0f, sy = 0.0f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float2 t = *reinterpret_cast<const float2 *>(p + (size_t)s * (SB_SLOTS * 2));
-    sx += t.x;
-    sy += t.y;
-  }
-  float *o = dproj + ((size_t)n * VP + v) * 3;
-  if (nslots > SB_SLOTS) {        // the overflow path may have hit this vertex' row with atomics
-    atomicAdd(&o[0], sx);
-    atomicAdd(&o[1], sy);
-  } else {
+  for (int slot = blockIdx.x * 256 + threadIdx.x; slot < nslots; slot += SB_SLOTS) {
+    const int v = __float_as_int(R[slot].w);
+    if (v < 0) continue;                                     // padding sentinel
+    const int win = slot / SB_SLOTS;
+    const float *p = part + ((size_t)n * nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (slot - win * SB_SLOTS) * 2;
+    float sx = 0.0f, sy = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float2 t = *reinterpret_cast<const float2 *>(p + (size_t)s * SB_NWIN * (SB_SLOTS * 2));
+      sx += t.x;
+      sy += t.y;
+    }
+    float *o = dproj + ((size_t)n * VP + v) * 3;
     o[0] = sx;
     o[1] = sy;
   }
@@ -903,15 +953,15 @@ size_t smplr_seg_workspace(int B, int VP, int W, int P, int K) {
   return smplr::seg_ws_layout(B, W, P, K).total;
 }
 
-int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, const int32_t *part_pos,
-                  const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,
-                  float *rec, void *stream) {
-  using namespace smplr;
+namespace smplr {
+static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fuse_vis, int grid_wh, int ref_compat,
+                        int B, int VP, int W, const int32_t *part_pos, const int32_t *part_off, int P, int K,
+                        void *workspace, float *seg, int16_t *arg, float *rec, void *stream) {
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
-                "smplr_seg_fwd: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", B, VP, W, P, K);
+                "%s: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, VP, W, P, K);
+  SMPLR_REQUIRE(!fuse_vis || (grid_wh > 0 && grid_wh <= 128), "%s: bad grid_wh=%d (max 128)", fn, grid_wh);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg && rec,
-                "smplr_seg_fwd: null pointer");
+  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg && rec, "%s: null pointer", fn);
   hipStream_t st = as_stream(stream);
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
@@ -920,24 +970,48 @@ int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, co
   int *goff = reinterpret_cast<int *>(base + ws.goff_off);
   int *lstart = reinterpret_cast<int *>(base + ws.lstart_off);
   uint2 *lrec = reinterpret_cast<uint2 *>(base + ws.lrec_off);
-  const size_t lds = (size_t)W * W * sizeof(int);
-  int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel), lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(seg_bin_kernel, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K, VP, W,
-                     S, G, goff, lstart, lrec);
-  SMPLR_LAUNCH_CHECK("smplr_seg_fwd(bin)");
+  size_t lds = (size_t)W * W * sizeof(int);
+  if (fuse_vis) {
+    lds = (size_t)((W * W + 1) & ~1) * sizeof(int) + (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
+    SMPLR_REQUIRE(lds <= 150 * 1024, "%s: pixel counters + grid + flags need %zu B of LDS (max 153600)", fn, lds);
+    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<true>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_bin_kernel<true>, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K, VP,
+                       W, S, G, goff, lstart, lrec, grid_wh, ref_compat);
+  } else {
+    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<false>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_bin_kernel<false>, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K,
+                       VP, W, S, G, goff, lstart, lrec, 0, 0);
+  }
+  SMPLR_LAUNCH_CHECK(fn);
   const int ntiles = (W * W + RT - 1) / RT;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
   hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RT * NG), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
                      seg, reinterpret_cast<short *>(arg));
-  SMPLR_LAUNCH_CHECK("smplr_seg_fwd");
+  SMPLR_LAUNCH_CHECK(fn);
   return 0;
+}
+}  // namespace smplr
+
+int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, const int32_t *part_pos,
+                  const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,
+                  float *rec, void *stream) {
+  return smplr::seg_fwd_impl("smplr_seg_fwd", proj, const_cast<float *>(mask), false, 0, 0, B, VP, W, part_pos,
+                             part_off, P, K, workspace, seg, arg, rec, stream);
+}
+
+int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int ref_compat,
+                      const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,
+                      float *mask, float *seg, int16_t *arg, float *rec, void *stream) {
+  return smplr::seg_fwd_impl("smplr_vis_seg_fwd", proj, mask, true, grid_wh, ref_compat, B, VP, W, part_pos,
+                             part_off, P, K, workspace, seg, arg, rec, stream);
 }
 
 size_t smplr_seg_bwd_workspace(int B, int W) {
   if (B <= 0 || W <= 0) return 0;
   const int nsplit = (W + smplr::SB_ROWS - 1) / smplr::SB_ROWS;
-  return (size_t)B * nsplit * smplr::SB_SLOTS * 2 * sizeof(float);
+  return (size_t)B * nsplit * smplr::SB_NWIN * smplr::SB_SLOTS * 2 * sizeof(float);
 }
 
 int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B, int VP, int W, int P, int K,
@@ -948,9 +1022,9 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
   if (B == 0) return 0;
   SMPLR_REQUIRE(dseg && arg && rec && dproj && workspace, "smplr_seg_bwd: null pointer");
   hipStream_t st = as_stream(stream);
-  SMPLR_HIP(hipMemsetAsync(dproj, 0, (size_t)B * VP * 3 * sizeof(float), st));
   const int nsplit = (W + SB_ROWS - 1) / SB_ROWS;
   const int S = seg_slots(P, K);
+  SMPLR_REQUIRE(S <= SB_NWIN * SB_SLOTS, "smplr_seg_bwd: %d record slots exceed %d", S, SB_NWIN * SB_SLOTS);
   hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(256), 0, st, dseg, reinterpret_cast<const short *>(arg),
                      reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, reinterpret_cast<float *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_seg_bwd");

@@ -11,12 +11,6 @@
 
 namespace smplr {
 
-__device__ __forceinline__ unsigned int orderable(float z) {
-  z += 0.0f;  // -0 -> +0 so that equal depths compare equal (tf.argmax treats them as ties)
-  const unsigned int b = __float_as_uint(z);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
 __global__ __launch_bounds__(1024) void visibility_kernel(const float *__restrict__ proj, int VP, int G,
                                                           int ref_compat, float *__restrict__ mask) {
   extern __shared__ unsigned long long zbuf[];                 // G*G keys

@@ -200,6 +200,26 @@ def _seg_fwd(proj, mask, W, pt: PartTable, out=None):
     return seg, arg, rec
 
 
+def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None):
+    """compute_mask + projects_to_seg in one call (smplr_vis_seg_fwd): -> mask, seg, arg, rec."""
+    lib = _lib.load()
+    B, VP = proj.shape[0], proj.shape[1]
+    if VP != pt.VP:
+        raise RuntimeError("projects has %d vertices but the part table expects %d" % (VP, pt.VP))
+    ws = _workspace(lib.smplr_seg_workspace(B, VP, W, pt.P, pt.K), proj)
+    if out is not None:
+        mask, seg, arg, rec = out
+    else:
+        mask = _empty((B, VP), proj)
+        seg = _empty((B, W, W, pt.P + 1), proj)
+        arg = _empty((B, W, W, 32), proj, torch.int16)
+        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
+    check(lib.smplr_vis_seg_fwd(ptr(proj), B, VP, W, int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos),
+                                ptr(pt.part_off), pt.P, pt.K, ptr(ws), ptr(mask), ptr(seg), ptr(arg), ptr(rec),
+                                stream()), "smplr_vis_seg_fwd")
+    return mask, seg, arg, rec
+
+
 def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable):
     lib = _lib.load()
     B = arg.shape[0]
@@ -479,8 +499,8 @@ class DecoderFn(torch.autograd.Function):
             _blend_fwd(coef[lo:hi], consts, out=v_posed[lo:hi])
             _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
                       out=(verts[lo:hi], proj[lo:hi]))
-            visibility(proj[lo:hi], grid_wh, ref_compat, out=mask[lo:hi])
-            _seg_fwd(proj[lo:hi], mask[lo:hi], W, pt, out=(seg[lo:hi], arg[lo:hi], rec[lo:hi]))
+            _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,
+                         out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]))
             if with_silh:
                 _silh_fwd(proj[lo:hi], W, out=(silh[lo:hi], sarg[lo:hi]))
 

@@ -526,3 +526,57 @@ def test_focal_loss_argument_errors():
     empty = ops.SoftmaxFocalFn.apply(torch.zeros(0, 4, 4, 32, device=dev()),
                                      torch.zeros(0, 16, dtype=torch.int64, device=dev()), None, 2.0)
     assert empty.shape == (0, 0) or empty.numel() == 0
+
+
+# ----------------------------------------------------------------------------------- fused mask + seg
+@pytest.mark.parametrize("vs,W,ref_compat", [(None, 48, True), (2, 64, True), (5, 48, False), (None, 50, True)])
+def test_vis_seg_fused_equals_separate(layer, vs, W, ref_compat):
+    """smplr_vis_seg_fwd == smplr_visibility -> smplr_seg_fwd, bit for bit (mask, seg, arg, records)."""
+    from ilps_amd import ops
+    _, _, proj = _decoder_inputs(layer, 5, W, 77, vs)
+    proj = proj.detach().contiguous()
+    pt = ops.get_part_table(vs or 1, proj.device, 6890)
+    mask = ops.visibility(proj, 64, ref_compat)
+    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt)
+    m2, s2, a2, r2 = ops._vis_seg_fwd(proj, W, pt, 64, ref_compat)
+    torch.cuda.synchronize()
+    assert torch.equal(mask, m2)
+    assert torch.equal(seg, s2)
+    # records that share a pixel are placed in arrival order (LDS atomics), so slot numbers of such
+    # records may differ between two launches: compare what the slots refer to
+    assert torch.equal(ops.argmin_vertices(arg, rec), ops.argmin_vertices(a2, r2))
+    assert torch.equal(arg[..., 0], a2[..., 0])
+    for b in range(proj.shape[0]):
+        nb = int(rec[b, -1, 0].view(torch.int32).item())
+        assert nb > 0 and nb == int(r2[b, -1, 0].view(torch.int32).item())
+        ra = rec[b, :nb].view(torch.int32).cpu().numpy()
+        rb = r2[b, :nb].view(torch.int32).cpu().numpy()
+        order = lambda r: r[np.lexsort((r[:, 0], r[:, 1], r[:, 3]))]
+        assert np.array_equal(order(ra), order(rb))
+
+
+def test_seg_backward_many_records_windows(layer, part_tables):
+    """A mesh whose record list (> 4096 slots: every vertex marked visible) needs several slot windows
+    in seg_bwd, next to a standard single-window mesh: repeatable to rounding, equal to the float64
+    oracle, z column and unreferenced vertices exactly 0 without any memset."""
+    from ilps_amd import ops
+    from oracle import torch_oracle as to
+    W = 48
+    _, _, proj = _decoder_inputs(layer, 2, W, 88)
+    proj = proj.detach().contiguous()
+    pt = ops.get_part_table(1, proj.device, 6890)
+    mask = torch.ones(2, 6890, device=proj.device)
+    mask[1] = ops.visibility(proj, 64, True)[1]                 # mesh 1: the standard single window
+    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt)
+    assert int(rec[0, -1, 0].view(torch.int32).item()) > 4096
+    g = t(np.random.default_rng(3).normal(0, 1, (2, W, W, 32)))
+    d1 = ops._seg_bwd(g, arg, rec, 6890, W, pt)
+    d2 = ops._seg_bwd(g, arg, rec, 6890, W, pt)
+    torch.cuda.synchronize()
+    assert torch.allclose(d1, d2, rtol=1e-4, atol=1e-6)
+    assert torch.all(d1[..., 2] == 0)
+    ids, off = part_tables[1]
+    po = torch.tensor(proj.cpu().numpy(), dtype=torch.float64, requires_grad=True)
+    (to.projects_to_seg(po, torch.tensor(mask.cpu().numpy(), dtype=torch.float64), W, ids, off)
+     * torch.tensor(g.cpu().numpy(), dtype=torch.float64)).sum().backward()
+    grad_close(d1.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(seg, windows)")
