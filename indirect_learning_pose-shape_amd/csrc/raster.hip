@@ -106,7 +106,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
                                                         uint2 *__restrict__ lrec, int vgrid, int ref_compat) {
   extern __shared__ int s_cnt[];   // npix (+ VIS: z-buffer keys, visible flags)
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
-  __shared__ int s_any_empty;
+  __shared__ int s_any_empty, s_nonunit;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int npix = W * W;
   const float *pj = proj + (size_t)n * VP * 3;
@@ -149,11 +149,12 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     for (int v = tid; v < VP; v += BIN_T) mk[v] = ((vis[v >> 5] >> (v & 31)) & 1u) ? 1.0f : 500.0f;
   }
   float4 *Gn = G + (size_t)n * S;
-  int *goffn = goff + (size_t)n * (P + 1);
+  int *goffn = goff + (size_t)n * (P + 2);
   int *lstartn = lstart + (size_t)n * (npix + 1);
   uint2 *lrecn = lrec + (size_t)n * K;
 
   if (tid <= P) s_poff[tid] = part_off[tid];
+  if (tid == 0) s_nonunit = 0;
   for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
   __syncthreads();
   const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
@@ -171,8 +172,12 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       const float m = VIS ? (((vis[pos >> 5] >> (pos & 31)) & 1u) ? 1.0f : 500.0f) : mk[pos];
       sl[j] = classify(pj, m, pos, W);
     }
-    if (sl[j].cls == 1) ++gcnt;
-    else if (sl[j].cls == 2) atomicAdd(&s_cnt[sl[j].pix], 1);
+    if (sl[j].cls == 1) {
+      ++gcnt;
+      if (sl[j].m != 1.0f) s_nonunit = 1;     // benign same-value race; read after the scans' barriers
+    } else if (sl[j].cls == 2) {
+      atomicAdd(&s_cnt[sl[j].pix], 1);
+    }
   }
   int gtotal;
   const int gbase = block_excl_scan(gcnt, s_wave, &gtotal);
@@ -255,7 +260,10 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       }
     }
   }
-  if (tid == 0) Gn[S - 1] = make_float4(__int_as_float(s_gpad[P] + lstartn[npix]), 0.f, 0.f, __int_as_float(-1));
+  // header: used slots | 1 if some far-reaching record has a weight other than 1 (else the pair loop skips m^2)
+  if (tid == 0) goffn[P + 1] = s_nonunit;
+  if (tid == 0)
+    Gn[S - 1] = make_float4(__int_as_float(s_gpad[P] + lstartn[npix]), __int_as_float(s_nonunit), 0.f, __int_as_float(-1));
   // sentinels in the padding
   if (tid < P) {
     const int cnt = s_gstart[tid + 1] - s_gstart[tid];
@@ -313,6 +321,48 @@ __device__ __forceinline__ void swait_group(f32x16s &v) {
   SMPLR_PAIR(make_float4(grp[8], grp[9], grp[10], grp[11]), (k) + 2)               \
   SMPLR_PAIR(make_float4(grp[12], grp[13], grp[14], grp[15]), (k) + 3)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Keys of two records against this lane's pixel (v_pk_add/mul/fma_f32).  Same roundings as
+// pair_key: sub, sub, mul, fma, mul; UNIT drops the final multiply when every weight is 1 (x*1 = x).
+template <bool UNIT>
+__device__ __forceinline__ f32x2 pair_key2(f32x2 u, f32x2 v, f32x2 m2, f32x2 fc2, f32x2 fr2) {
+  const f32x2 du = u - fc2, dv = v - fr2;
+  const f32x2 t = dv * dv;
+  const f32x2 d2 = __builtin_elementwise_fma(du, du, t);
+  return UNIT ? d2 : d2 * m2;
+}
+
+// Records [beg, end) of the block's LDS copy (field-major: u | v | m^2, NREC floats each) against
+// this lane's pixel, 4 records per step: only the group minimum is tracked (strict '<': the first
+// minimal group wins); bav = byte offset of the winning group (the LDS address operand is a VGPR
+// anyway, so it doubles as the tracked id).
+#define SMPLR_LDS_GROUP(off, fld) \
+  (*reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(base + (off) + (fld) * NREC * 4, 16)))
+template <bool UNIT>
+__device__ __forceinline__ float group_min(const char *base, unsigned av, f32x2 fc2, f32x2 fr2) {
+  const f32x4 u = SMPLR_LDS_GROUP(av, 0), v = SMPLR_LDS_GROUP(av, 1);
+  f32x4 m = {1.f, 1.f, 1.f, 1.f};
+  if (!UNIT) m = SMPLR_LDS_GROUP(av, 2);
+  const f32x2 k01 = pair_key2<UNIT>(u.xy, v.xy, m.xy, fc2, fr2);
+  const f32x2 k23 = pair_key2<UNIT>(u.zw, v.zw, m.zw, fc2, fr2);
+  return fminf(fminf(k01.x, k01.y), fminf(k23.x, k23.y));
+}
+template <bool UNIT>
+__device__ __forceinline__ void lds_scan(const char *base, int beg, int end, f32x2 fc2, f32x2 fr2, float &best,
+                                         unsigned &bav) {
+  unsigned av = (unsigned)beg * 4u;
+  asm volatile("" : "+v"(av));
+  for (int k = beg; k < end; k += GP) {
+    const float ma = group_min<UNIT>(base, av, fc2, fr2);
+    const bool la = ma < best;
+    best = la ? ma : best;
+    bav = la ? av : bav;
+    av += GP * 4;
+  }
+}
+
 // Block = 256 pixels of one mesh x 4 channel groups = 16 waves: wave (g, w) evaluates channels
 // [8g, 8g+8) for pixels [64w, 64w+64) of the tile.  What bounds this kernel at small batch is the
 // per-wave dependent chain (scalar loads -> VALU -> exp -> LDS, part after part), so the 32 channels
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   __shared__ float sS[NG * RT * TLD];
   __shared__ short sA[NG * RT * TLD];
   __shared__ float sSum[NG][RT];
-  __shared__ float4 sR[NREC];
+  __shared__ f32x4 sRec[3 * NREC / 4];   // records, field-major: u[NREC] | v[NREC] | m^2[NREC]
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
   const int bid = blockIdx.x;
@@ -344,46 +394,62 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   const int r = qc / W, c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
   const float4 *Gn = G + (size_t)n * S;
-  const int *goffn = goff + (size_t)n * (P + 1);
+  const int *goffn = goff + (size_t)n * (P + 2);
   const int C = P + 1;
+  // everything the block needs from global memory is requested up front (one round trip): the
+  // pixel's local-record range, the list length, the unit-weight flag, the part offsets (-> LDS)
   const int l0 = lstart[(size_t)n * (npix + 1) + qc], l1 = lstart[(size_t)n * (npix + 1) + qc + 1];
   const uint2 *lrecn = lrec + (size_t)n * K;
   const int lbase = goffn[P];
-  // the mesh's global record list (typically ~600 records) is copied to LDS once per block and read
-  // by its 16 waves with broadcast ds_read_b128 (in-order, counted waits); longer lists use the
-  // scalar-load path below.  Both evaluate the same fp32 expressions.
+  const bool unit_m = goffn[P + 1] == 0;                 // every far-reaching weight is 1 (block-uniform)
+  __shared__ int sOff[40];
+  if (tid <= P) sOff[tid] = goffn[tid];
+  // the mesh's global record list (typically ~600 records) is copied to LDS once per block, one
+  // array per field, and read by its 16 waves four records at a time with broadcast ds_read_b128
+  // (in-order, counted waits); longer lists use the scalar-load path below.  Both evaluate the
+  // same fp32 expressions.
   const bool in_lds = lbase <= NREC;                     // block-uniform
   if (in_lds) {
-    for (int i2 = tid; i2 < lbase; i2 += RT * NG) sR[i2] = Gn[i2];
-    __syncthreads();
+    for (int i2 = tid; i2 < lbase; i2 += RT * NG) {
+      const float4 t = Gn[i2];
+      float *f = reinterpret_cast<float *>(sRec);
+      f[i2] = t.x;
+      f[NREC + i2] = t.y;
+      f[2 * NREC + i2] = t.z;
+    }
   }
+  __syncthreads();
+  // the first two local records of this pixel are fetched now and used after the pair loop
+  const uint2 lr0 = lrecn[min(l0, K - 1)], lr1 = lrecn[min(l0 + 1, K - 1)];
+  const f32x2 fc2 = {fc, fc}, fr2 = {fr, fr};
   float *myS = &sS[(g * RT + pt) * TLD];
   short *myA = &sA[(g * RT + pt) * TLD];
   const int ch0 = g * HC;
 
   {
     const int p_first = (ch0 == 0) ? 0 : ch0 - 1;
-    int beg = goffn[p_first < P ? p_first : P];
-    int nxt = goffn[(p_first + 1) < P ? (p_first + 1) : P];     // end of the current part
+    int beg = __builtin_amdgcn_readfirstlane(sOff[p_first < P ? p_first : P]);
+    int nxt = __builtin_amdgcn_readfirstlane(sOff[(p_first + 1) < P ? (p_first + 1) : P]);   // end of the current part
     for (int j = 0; j < HC; ++j) {
       const int ch = ch0 + j;
       if (ch == 0 || ch >= C) { myS[j] = 0.0f; myA[j] = -1; continue; }
       const int p = ch - 1;
       const int end = nxt;
-      nxt = goffn[opaque((p + 2) < P ? (p + 2) : P)];           // prefetch the next part's end
+      nxt = __builtin_amdgcn_readfirstlane(sOff[(p + 2) < P ? (p + 2) : P]);   // the next part's end
       float best = INFINITY;
       int bslot = -1;
       if (in_lds) {
         if (beg < end) {
-          float4 r0 = sR[beg], r1 = sR[beg + 1], r2 = sR[beg + 2], r3 = sR[beg + 3];
-          for (int k = beg; k < end; k += GP) {
-            const int kn = (k + GP < end) ? k + GP : k;         // next group in flight during this one
-            const float4 n0 = sR[kn], n1 = sR[kn + 1], n2 = sR[kn + 2], n3 = sR[kn + 3];
-            SMPLR_PAIR(r0, k)
-            SMPLR_PAIR(r1, k + 1)
-            SMPLR_PAIR(r2, k + 2)
-            SMPLR_PAIR(r3, k + 3)
-            r0 = n0; r1 = n1; r2 = n2; r3 = n3;
+          unsigned bav = 0xffffffffu;
+          const char *base = reinterpret_cast<const char *>(sRec);
+          if (unit_m) lds_scan<true>(base, beg, end, fc2, fr2, best, bav);
+          else lds_scan<false>(base, beg, end, fc2, fr2, best, bav);
+          // the winning group is looked at once more for the first record that attains the minimum
+          if (bav != 0xffffffffu) {
+            const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1), m = SMPLR_LDS_GROUP(bav, 2);
+            const f32x2 k01 = pair_key2<false>(u.xy, v.xy, m.xy, fc2, fr2);
+            const f32x2 k23 = pair_key2<false>(u.zw, v.zw, m.zw, fc2, fr2);
+            bslot = (int)(bav >> 2) + ((k01.x == best) ? 0 : (k01.y == best) ? 1 : (k23.x == best) ? 2 : 3);
           }
         }
       } else if (beg < end) {
@@ -412,7 +478,7 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   }
   // merge this pixel's local records (invisible vertices that round to this pixel)
   for (int i = l0; i < l1; ++i) {
-    const uint2 rec = lrecn[i];
+    const uint2 rec = (i == l0) ? lr0 : (i == l0 + 1) ? lr1 : lrecn[i];
     const int ch = 1 + (int)rec.y;
     if (ch >= ch0 && ch < ch0 + HC) {
       const float sc = fast_exp_neg(__uint_as_float(rec.x));
@@ -935,7 +1001,7 @@ static SegWs seg_ws_layout(int B, int W, int P, int K) {
   SegWs w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  w.goff_off = take((size_t)B * (P + 1) * sizeof(int));
+  w.goff_off = take((size_t)B * (P + 2) * sizeof(int));   // part offsets [P+1] | unit-weight flag
   w.lstart_off = take((size_t)B * ((size_t)W * W + 1) * sizeof(int));
   w.lrec_off = take((size_t)B * K * sizeof(uint2));
   w.total = off;
