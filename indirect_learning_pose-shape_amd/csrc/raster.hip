@@ -408,16 +408,17 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   // array per field, and read by its 16 waves four records at a time with broadcast ds_read_b128
   // (in-order, counted waits); longer lists use the scalar-load path below.  Both evaluate the
   // same fp32 expressions.
-  const bool in_lds = lbase <= NREC;                     // block-uniform
-  if (in_lds) {
-    for (int i2 = tid; i2 < lbase; i2 += RT * NG) {
-      const float4 t = Gn[i2];
-      float *f = reinterpret_cast<float *>(sRec);
-      f[i2] = t.x;
-      f[NREC + i2] = t.y;
-      f[2 * NREC + i2] = t.z;
-    }
+  static_assert(RT * NG == NREC, "one record per thread");
+  {
+    // thread i copies record i before the list length is even known (slots beyond it hold stale
+    // bytes nobody reads), so the copy shares the first round trip to memory
+    const float4 t = Gn[min(tid, S - 1)];
+    float *f = reinterpret_cast<float *>(sRec);
+    f[tid] = t.x;
+    f[NREC + tid] = t.y;
+    f[2 * NREC + tid] = t.z;
   }
+  const bool in_lds = lbase <= NREC;                     // block-uniform
   __syncthreads();
   // the first two local records of this pixel are fetched now and used after the pair loop
   const uint2 lr0 = lrecn[min(l0, K - 1)], lr1 = lrecn[min(l0 + 1, K - 1)];
