@@ -70,8 +70,8 @@ def stage_breakdown(x, consts, pt, W, reps=20):
     res = {}
     coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts)
     res["pose_fwd"] = event_time_ms(lambda: ops._pose_fwd(x, 4, consts), reps, st)
-    v_posed = ops._blend_fwd(coef, consts)
-    res["blend_fwd"] = event_time_ms(lambda: ops._blend_fwd(coef, consts), reps, st)
+    v_posed = ops._blend_fwd(coef, consts, x.shape[0])
+    res["blend_fwd"] = event_time_ms(lambda: ops._blend_fwd(coef, consts, x.shape[0]), reps, st)
     verts, proj = ops._skin_fwd(v_posed, A, consts, cam=x)
     res["skin_fwd"] = event_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
     mask = ops.visibility(proj)
@@ -250,7 +250,7 @@ def main():
                     traffic = None
             # executed work: pairs actually evaluated (visible records only) x ~10 FLOP (9 VALU ops, one an FMA)
             c0 = ops._pose_fwd(x, 4, consts)
-            pj = ops._skin_fwd(ops._blend_fwd(c0[0], consts), c0[3], consts, cam=x)[1]
+            pj = ops._skin_fwd(ops._blend_fwd(c0[0], consts, x.shape[0]), c0[3], consts, cam=x)[1]
             nvis = float((ops.visibility(pj) == 1.0).sum().item()) / B
             executed = (W * W * nvis * 10.0 * B) / t_seg / 1e12
             line["roofline"] = {

@@ -47,9 +47,12 @@ const char *smplr_last_error(void);
  * (J = J_template + J_dirs * beta, algebraically :106-115) and the 24-joint kinematic chain
  * (batch_global_rigid_transformation, :168-228).
  *   x     (B, x_stride)  rows [cam(num_cam) | theta(72) | beta(10)]
- *   coef  (B, 220)       [beta(10) | pose_feature(207) | 0,0,0]  - the blend GEMM's A operand
+ *   coef  (220, ld)      k-MAJOR, ld = smplr_coef_ld(B) = B rounded up to 32: column n =
+ *                        [beta(10) | pose_feature(207) | 0,0,0] of mesh n - the blend GEMM's A operand,
+ *                        laid out so that the matrix cores read it without a transpose
  *   Rs    (B,24,9)  J (B,24,3)  A (B,24,12) = rows 0..2 of the reference's (4,4) A
  *   J_transformed (B,24,3)  (batch_smpl.py:131, :216)                                      */
+int smplr_coef_ld(int B);
 int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B,
                    const float *J_template, const float *J_dirs, const int32_t *parents,
                    float *coef, float *Rs, float *J, float *A, float *J_transformed,
@@ -65,7 +68,8 @@ int smplr_pose_bwd(const float *x, int x_stride, int num_cam, int B,
                    const float *dcam, float *dx, void *stream);
 
 /* Blend shapes (batch_smpl.py:106-108 and :126-128 as ONE fp32-MFMA GEMM):
- *   v_posed (B,N3) = coef (B,220) x blend (220,N3) + v_template (N3),  N3 = 3*V.
+ *   v_posed (B,N3) = coef^T x blend (220,N3) + v_template (N3),  N3 = 3*V; coef (220, smplr_coef_ld(B))
+ *   k-major as smplr_pose_fwd writes it.
  * blend rows 0..9 = shapedirs, 10..216 = posedirs, 217..219 = 0.                            */
 int smplr_blend_fwd(const float *coef, const float *blend, const float *v_template,
                     int B, int N3, float *v_posed, void *stream);

@@ -25,6 +25,7 @@ I = c_int
 SIGNATURES = {
     "smplr_abi_version": (c_int, []),
     "smplr_last_error": (c_char_p, []),
+    "smplr_coef_ld": (c_int, [I]),
     "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P]),
     "smplr_pose_bwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "smplr_blend_fwd": (c_int, [P, P, P, I, I, P, P]),

@@ -6,11 +6,8 @@
 // Reference: keras_smpl/batch_smpl.py:106-108 (shape blend, K.dot) and :126-128 (pose blend,
 // K.dot) fused into one contraction over [beta | pose_feature].
 //
-// Forward tiling: workgroup = 4 waves = 128 meshes x one 96-column strip, each wave a 32x96 tile
-// (3 accumulator tiles) of a different mesh tile.  coef^T of all 128 meshes sits in LDS
-// ([tile][k][mesh], row stride 33 -> conflict-free both ways); the B operand needs no transpose
-// so each wave reads blend rows straight from global in MFMA layout (two 128-B row segments
-// per load) and the four waves share those lines through L1.
+// Forward tiling: workgroup = 4 waves = 128 meshes x one 96-column tile, each wave a 32x96 tile
+// (3 accumulators); both operands are read from global memory directly in MFMA layout (no LDS).
 //
 // Backward tiling: workgroup = 32 meshes x all 220 outputs (7 tiles) x one slice of columns,
 // against the TRANSPOSED constant blendT (N3 x 224) so that no operand of the big matrix needs a
@@ -23,118 +20,98 @@ namespace smplr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KP = SMPLR_KPAD;  // 220
-constexpr int FW_BM = 32, FW_WN = 96;
-constexpr int A_LD = 33;
+constexpr int FW_BM = 32;
+constexpr int FW_NT = 3;      // column tiles (accumulators) per wave: B is loaded NT columns per lane
+constexpr int FW_BN = 32 * FW_NT;
+constexpr int FW_NB = 5;      // k-steps (of 2 rows) per register batch: 22 batches x 5 x 2 = 220
+constexpr int FW_DEPTH = 6;   // batches in flight ahead of the one being multiplied (60 loads <= 63)
 
-// grid (column strips of 96, groups of 128 meshes); the 4 waves of a block are the 4 mesh tiles of
-// ONE strip, so they issue identical B-operand loads and the CU's L1 serves three of them: the
-// big matrix crosses L2->L1 once per 128 meshes instead of once per 32.
+template <int N> struct VecN;
+template <> struct VecN<1> { typedef float type; };
+template <> struct VecN<2> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct VecN<3> { typedef float type __attribute__((ext_vector_type(3), aligned(4))); };
+template <> struct VecN<4> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+
+// Forward: grid (column tiles of 96, groups of 128 meshes); workgroup = 4 waves = the 4 mesh tiles
+// of ONE column tile, each wave three 32x32 accumulators.  Both operands are read straight from
+// global memory in MFMA layout, nothing is staged or transposed:
+//   A (coef, k-major (220, ldc)): lane (i, h) reads coef[2s+h][m0+i]
+//   B (blend, row-major (220, N3)): lane (i, h) reads blend[2s+h][c0 + 3i .. 3i+2] with ONE dwordx3
+//     load; accumulator t owns the columns c0 + 3i + t (any column permutation is a valid tile)
+// so every wave-load covers whole contiguous row segments and a k-step costs 2 loads for 3 MFMAs.
+// A wave may have 63 loads outstanding: 6 batches of 5 k-steps (60 loads = 90 MFMAs ~ 2.4 us of
+// matrix work) run ahead of the batch being multiplied, which covers an HBM round trip without
+// help from other waves (there is about one wave per SIMD).  The four waves issue identical B
+// loads (L1 serves three of them), coef (112 KB) stays in L2.  Measured alone: 16 us, against
+// 29 us for the previous tiling that staged coef^T through 116 KB of LDS per workgroup.
 __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict__ coef,
                                                         const float *__restrict__ blend,
                                                         const float *__restrict__ vt, int B, int N3,
-                                                        float *__restrict__ out) {
-  extern __shared__ float sAall[];          // 4 x [220][33]: coef^T of the 4 mesh tiles
-  const int strip = blockIdx.x, mg = blockIdx.y;
+                                                        int ldc, float *__restrict__ out) {
+  typedef typename VecN<FW_NT>::type bvec;
+  constexpr int NBATCH = KP / (2 * FW_NB);
+  static_assert(NBATCH * FW_NB * 2 == KP, "batches cover K exactly");
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int mbase = mg * 4 * FW_BM;
-  {
-    const int rows = min(4 * FW_BM, B - mbase);          // meshes present in this group
-    const float *src = coef + (size_t)mbase * KP;        // contiguous rows*220 floats
-    // 28,160 contiguous floats, 110 per thread, in 2 batches of 55 loads in flight (a batch costs one
-    // memory round trip however many loads it holds); (mesh, k) of element e = tid + 256 u advance
-    // incrementally (256 = 220 + 36) instead of dividing per element
-    const int nvalid = rows * KP;
-    int i = tid / KP, k = tid - i * KP;
-    for (int e0 = tid; e0 < 4 * FW_BM * KP; e0 += 256 * 55) {
-      float v[55];
-#pragma unroll
-      for (int u = 0; u < 55; ++u) {
-        const int e = e0 + u * 256;
-        const float ld = src[min(e, nvalid - 1)];       // unconditional (clamped) load, select afterwards
-        v[u] = (e < nvalid) ? ld : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < 55; ++u) {
-        sAall[(i >> 5) * (KP * A_LD) + k * A_LD + (i & 31)] = v[u];
-        k += 36; i += 1;
-        if (k >= KP) { k -= KP; i += 1; }
-      }
-    }
-  }
-  __syncthreads();
-  const int m0 = mbase + wave * FW_BM;
+  const int m0 = (blockIdx.y * 4 + wave) * FW_BM;
   if (m0 >= B) return;                                   // this wave's mesh tile is empty
-  const float *sA = sAall + wave * (KP * A_LD);
-
   const int i = lane & 31, h = lane >> 5;
-  const int cw = strip * FW_WN;
-  int col[3];
+  const int c = blockIdx.x * FW_BN + FW_NT * i;
+  const int cc = c + FW_NT <= N3 ? c : N3 - FW_NT;       // clamped; discarded in the epilogue
+  const float *ap = coef + (size_t)h * ldc + m0 + i;     // m0 + i < ldc (padded columns are never stored)
+  const float *bp = blend + (size_t)h * N3 + cc;
+  const size_t arow = (size_t)ldc, brow = (size_t)N3;
+
+  f32x16 acc[FW_NT];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int c = cw + t * 32 + i;
-    col[t] = c < N3 ? c : N3 - 1;  // clamped; discarded in the epilogue
-  }
-  f32x16 acc[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < FW_NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // B operand double-buffered in registers: batch q+1 (11 k-steps = 33 loads) is in flight while
-  // the 33 MFMAs of batch q run, so one wave per SIMD is enough to cover the L2/HBM latency.
-  constexpr int NB = 11;                       // k-steps per batch; 10 batches x 22 rows = 220
-  float b0[NB][3], b1[NB][3], b2[NB][3];
-  auto load_batch = [&](float (&b)[NB][3], int kb) {
+  // ring of DEPTH+1 register batches, fully unrolled (static indices); sched_barrier pins each
+  // batch of loads above the MFMAs it overlaps (left alone the scheduler sinks loads to their uses)
+  float a[FW_DEPTH + 1][FW_NB];
+  bvec b[FW_DEPTH + 1][FW_NB];
+#define SMPLR_LOAD_BATCH(slot, q)                                                        \
+  _Pragma("unroll") for (int s2 = 0; s2 < FW_NB; ++s2) {                                 \
+    const int kk = 2 * ((q) * FW_NB + s2);                                               \
+    a[slot][s2] = ap[(size_t)kk * arow];                                                 \
+    b[slot][s2] = *reinterpret_cast<const bvec *>(bp + (size_t)kk * brow);               \
+  }
 #pragma unroll
-    for (int s2 = 0; s2 < NB; ++s2) {
-      const float *brow = blend + (size_t)(kb + 2 * s2 + h) * N3;
-#pragma unroll
-      for (int t = 0; t < 3; ++t) b[s2][t] = brow[col[t]];
-    }
-  };
-  auto mma_batch = [&](const float (&b)[NB][3], int kb) {
-    float a[NB];                                // the batch's A operands first: no LDS wait per k-step
-#pragma unroll
-    for (int s2 = 0; s2 < NB; ++s2) a[s2] = sA[(kb + 2 * s2 + h) * A_LD + i];
-#pragma unroll
-    for (int s2 = 0; s2 < NB; ++s2) {
-#pragma unroll
-      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2][t], acc[t], 0, 0, 0);
-    }
-  };
-  // Three B-operand batches rotate: batches q+1 and q+2 (66 loads) are in flight under batch q's
-  // 33 MFMAs (~1 us), which is what an L2-miss round trip takes.  sched_barrier pins the order:
-  // left alone the scheduler sinks the loads next to their uses (8 in flight) and the loop stalls.
-#define SMPLR_STEP(cur, nxt2, q)                                   \
-  if ((q) + 2 < 10) load_batch(nxt2, ((q) + 2) * 2 * NB);         \
-  __builtin_amdgcn_sched_barrier(0);                               \
-  mma_batch(cur, (q) * 2 * NB);                                    \
+  for (int q = 0; q < FW_DEPTH; ++q) { SMPLR_LOAD_BATCH(q % (FW_DEPTH + 1), q) }
   __builtin_amdgcn_sched_barrier(0);
-  load_batch(b0, 0);
-  load_batch(b1, 2 * NB);
-  __builtin_amdgcn_sched_barrier(0);
-  SMPLR_STEP(b0, b2, 0)
-  SMPLR_STEP(b1, b0, 1)
-  SMPLR_STEP(b2, b1, 2)
-  SMPLR_STEP(b0, b2, 3)
-  SMPLR_STEP(b1, b0, 4)
-  SMPLR_STEP(b2, b1, 5)
-  SMPLR_STEP(b0, b2, 6)
-  SMPLR_STEP(b1, b0, 7)
-  SMPLR_STEP(b2, b1, 8)
-  SMPLR_STEP(b0, b2, 9)
-#undef SMPLR_STEP
+#pragma unroll
+  for (int q = 0; q < NBATCH; ++q) {
+    if (q + FW_DEPTH < NBATCH) { SMPLR_LOAD_BATCH((q + FW_DEPTH) % (FW_DEPTH + 1), q + FW_DEPTH) }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < FW_NB; ++s2)
+#pragma unroll
+      for (int t = 0; t < FW_NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % (FW_DEPTH + 1)][s2], b[q % (FW_DEPTH + 1)][s2][t],
+                                                      acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SMPLR_LOAD_BATCH
 
+  float base[FW_NT];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int c = cw + t * 32 + i;
-    if (c < N3) {
-      const float base = vt[c];
+  for (int t = 0; t < FW_NT; ++t) base[t] = vt[min(c + t, N3 - 1)];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int m = m0 + row;
-        if (m < B) out[(size_t)m * N3 + c] = acc[t][r] + base;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int m = m0 + row;
+    if (m < B) {
+      float *o = out + (size_t)m * N3 + c;
+      if (c + FW_NT <= N3) {
+        bvec v;
+#pragma unroll
+        for (int t = 0; t < FW_NT; ++t) v[t] = acc[t][r] + base[t];
+        *reinterpret_cast<bvec *>(o) = v;
+      } else {
+#pragma unroll
+        for (int t = 0; t < FW_NT; ++t)
+          if (c + t < N3) o[t] = acc[t][r] + base[t];
       }
     }
   }
@@ -305,16 +282,9 @@ int smplr_blend_fwd(const float *coef, const float *blend, const float *v_templa
   SMPLR_REQUIRE(B >= 0 && N3 > 0, "smplr_blend_fwd: bad sizes B=%d N3=%d", B, N3);
   if (B == 0) return 0;
   SMPLR_REQUIRE(coef && blend && v_template && v_posed, "smplr_blend_fwd: null pointer");
-  const int nstrips = (N3 + FW_WN - 1) / FW_WN, ngroups = (B + 4 * FW_BM - 1) / (4 * FW_BM);
-  const size_t lds = (size_t)4 * KP * A_LD * sizeof(float);     // 116,160 B
-  static bool attr_set = false;
-  if (!attr_set) {
-    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blend_fwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(blend_fwd_kernel, dim3(nstrips, ngroups), dim3(256), lds, as_stream(stream), coef, blend,
-                     v_template, B, N3, v_posed);
+  const int ntiles = (N3 + FW_BN - 1) / FW_BN, ngroups = (B + 4 * FW_BM - 1) / (4 * FW_BM);
+  hipLaunchKernelGGL(blend_fwd_kernel, dim3(ntiles, ngroups), dim3(256), 0, as_stream(stream), coef, blend,
+                     v_template, B, N3, smplr_coef_ld(B), v_posed);
   SMPLR_LAUNCH_CHECK("smplr_blend_fwd");
   return 0;
 }

@@ -99,7 +99,7 @@ __device__ __forceinline__ void rodrigues_bwd(const float t[3], const float dR[9
 __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
     const float *__restrict__ x, int x_stride, int num_cam, int B,
     const float *__restrict__ J_template, const float *__restrict__ J_dirs,
-    const int *__restrict__ parents, float *__restrict__ coef, float *__restrict__ Rs_out,
+    const int *__restrict__ parents, float *__restrict__ coef, int ldc, float *__restrict__ Rs_out,
     float *__restrict__ J_out, float *__restrict__ A_out, float *__restrict__ newJ_out) {
   __shared__ PoseLds lds[MPB];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
   const float *beta = xr + num_cam + 72;
 
   if (live) {
-    float *cf = coef + (size_t)n * SMPLR_KPAD;
+    float *cf = coef + n;                    // k-major: coef[k][n], row stride ldc
     if (lane < 24) {
       float t[3] = {xr[num_cam + 3 * lane], xr[num_cam + 3 * lane + 1], xr[num_cam + 3 * lane + 2]};
       float R[9];
@@ -123,11 +123,11 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
       if (lane >= 1) {
 #pragma unroll
         for (int e = 0; e < 9; ++e)
-          cf[10 + 9 * (lane - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+          cf[(size_t)(10 + 9 * (lane - 1) + e) * ldc] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
       }
     }
-    if (lane < 10) cf[lane] = beta[lane];
-    if (lane >= 10 && lane < 13) cf[207 + lane] = 0.0f;  // 217..219
+    if (lane < 10) cf[(size_t)lane * ldc] = beta[lane];
+    if (lane >= 10 && lane < 13) cf[(size_t)(207 + lane) * ldc] = 0.0f;  // 217..219
     for (int e = lane; e < 72; e += 64) {
       float acc = J_template[e];
 #pragma unroll
@@ -301,6 +301,8 @@ extern "C" {
 int smplr_abi_version(void) { return SMPLR_ABI_VERSION; }
 const char *smplr_last_error(void) { return smplr::g_err; }
 
+int smplr_coef_ld(int B) { return B > 0 ? (B + 31) / 32 * 32 : 0; }
+
 int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B, const float *J_template,
                    const float *J_dirs, const int32_t *parents, float *coef, float *Rs, float *J,
                    float *A, float *J_transformed, void *stream) {
@@ -311,7 +313,8 @@ int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B, const float
   SMPLR_REQUIRE(x && J_template && J_dirs && parents && coef && Rs && J && A && J_transformed,
                 "smplr_pose_fwd: null pointer");
   hipLaunchKernelGGL(pose_fwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
-                     x, x_stride, num_cam, B, J_template, J_dirs, parents, coef, Rs, J, A, J_transformed);
+                     x, x_stride, num_cam, B, J_template, J_dirs, parents, coef, smplr_coef_ld(B), Rs, J, A,
+                     J_transformed);
   SMPLR_LAUNCH_CHECK("smplr_pose_fwd");
   return 0;
 }

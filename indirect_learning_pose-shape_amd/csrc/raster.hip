@@ -546,7 +546,7 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
 constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators
 constexpr int SB_NWIN = 5;       // slot windows the partial buffer holds: S <= 20480
 constexpr int SB_ROWS = 8;       // rows (strips) per block
-constexpr int SB_U = 4;          // pixels in flight per lane
+constexpr int SB_U = 8;          // pixels in flight per lane
 
 __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float sy) {
   if (cur >= 0 && (sx != 0.0f || sy != 0.0f)) {

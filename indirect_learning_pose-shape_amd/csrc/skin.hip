@@ -55,15 +55,22 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
   }
   const bool sampled = (vs <= 1) || (v % vs == 0);
   const int vp_idx = (vs <= 1) ? v : v / vs;
-  for (int mi = 0; mi < SK_MB; ++mi) {
-    const int n = blockIdx.y * SK_MB + mi;   // wave-uniform
-    if (n >= B) break;
+  static_assert(SK_MB == 1, "one mesh per block");
+  {
+    const int n = blockIdx.y;                // block-uniform
     const float *An = A + (size_t)n * 288;
+    // every global operand is requested before the barrier below: one round trip per block
+    const float *vp = v_posed + ((size_t)n * V + vc) * 3;
+    const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+    if (proj) {
+      const float *c = cam + (size_t)n * x_stride;
+      c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
+    }
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.0f;
     if (SPARSE) {
-      if (mi > 0) __syncthreads();
       if (threadIdx.x < 72) sAj[threadIdx.x] = reinterpret_cast<const float4 *>(An)[threadIdx.x];
       __syncthreads();
 #pragma unroll
@@ -80,8 +87,6 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
     }
-    const float *vp = v_posed + ((size_t)n * V + vc) * 3;
-    const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
     const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
     const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
     const float Z = T[8] * p0 + T[9] * p1 + T[10] * p2 + T[11];
@@ -91,10 +96,9 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
         o[0] = X; o[1] = Y; o[2] = Z;
       }
       if (proj && sampled) {
-        const float *c = cam + (size_t)n * x_stride;
         float *o = proj + ((size_t)n * VP + vp_idx) * 3;
-        o[0] = c[2] + X * c[0];
-        o[1] = c[3] + Y * c[1];
+        o[0] = c2 + X * c0;
+        o[1] = c3 + Y * c1;
         o[2] = Z;
       }
     }
@@ -124,6 +128,12 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   const bool sampled = (vs <= 1) || (v % vs == 0);
   const int vpi = (vs <= 1) ? v : v / vs;
 
+  static_assert(SKB_MB == 1, "one mesh per block");
+  const int n = blockIdx.y;                   // block-uniform
+  // Every global operand of the block is requested here, before the first barrier: the weights,
+  // the mesh's joint matrix, the vertex and its incoming gradients (clamped, unconditional loads:
+  // a per-lane condition around a load costs a branch and a drained vmcnt each), so the block
+  // pays one round trip to memory instead of three.
   float w[24];
   {
     const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
@@ -133,8 +143,6 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
       w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
     }
   }
-#pragma unroll
-  for (int j = 0; j < 24; ++j) sW[tid * SKB_WLD + j] = w[j];
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
   int jx[4] = {0, 0, 0, 0};
   if (SPARSE) {
@@ -143,19 +151,32 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     w4[0] = ww.x; w4[1] = ww.y; w4[2] = ww.z; w4[3] = ww.w;
     jx[0] = (int)jj.x; jx[1] = (int)jj.y; jx[2] = (int)jj.z; jx[3] = (int)jj.w;
   }
+  const float4 aj = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid < 72 ? tid : 71];
+  const float *vp = v_posed + ((size_t)n * V + vc) * 3;
+  const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+  float gv0 = 0.f, gv1 = 0.f, gv2 = 0.f, gp0 = 0.f, gp1 = 0.f, gp2 = 0.f, ck0 = 0.f, ck1 = 0.f;
+  if (dverts) {                               // block-uniform
+    const float *d = dverts + ((size_t)n * V + vc) * 3;
+    gv0 = d[0]; gv1 = d[1]; gv2 = d[2];
+  }
+  if (dproj) {                                // block-uniform
+    const float *d = dproj + ((size_t)n * VP + min(vpi, VP - 1)) * 3;
+    const float *c = cam + (size_t)n * x_stride;
+    gp0 = d[0]; gp1 = d[1]; gp2 = d[2];
+    ck0 = c[0]; ck1 = c[1];
+  }
+#pragma unroll
+  for (int j = 0; j < 24; ++j) sW[tid * SKB_WLD + j] = w[j];
+  if (tid < 72) sAj[tid] = aj;
   __syncthreads();
 
   const int li = lane & 15, lk = lane >> 4;
   const int cr = li >> 2, cc = li & 3;   // dT component j = li = r*4+c  (valid for li < 12)
 
-  for (int mi = 0; mi < SKB_MB; ++mi) {
-    const int n = blockIdx.y * SKB_MB + mi;     // block-uniform
-    if (n >= B) break;
+  {
     // T = sum_j w_j A_j with the mesh's joint matrix staged in LDS (broadcast ds_read_b128) and
     // w_j taken from LDS as well: as scalar operands the 288 matrix entries need more SGPRs than
     // exist (the compiler then spills through v_readlane or falls back to 288 vector loads).
-    if (tid < 72) sAj[tid] = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid];
-    __syncthreads();
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.0f;
@@ -168,23 +189,16 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
       T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
       T[8] = fmaf(wj, r2.x, T[8]); T[9] = fmaf(wj, r2.y, T[9]); T[10] = fmaf(wj, r2.z, T[10]); T[11] = fmaf(wj, r2.w, T[11]);
     }
-    const float *vp = v_posed + ((size_t)n * V + vc) * 3;
-    const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
 
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
     if (live) {
-      if (dverts) {
-        const float *d = dverts + ((size_t)n * V + v) * 3;
-        g0 = d[0]; g1 = d[1]; g2 = d[2];
-      }
+      g0 = gv0; g1 = gv1; g2 = gv2;
       if (dproj && sampled) {
-        const float *d = dproj + ((size_t)n * VP + vpi) * 3;
-        const float *c = cam + (size_t)n * x_stride;
-        const float du = d[0], dv = d[1];
+        const float du = gp0, dv = gp1;
         const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
         const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
-        g0 += c[0] * du; g1 += c[1] * dv; g2 += d[2];
+        g0 += ck0 * du; g1 += ck1 * dv; g2 += gp2;
         dku = X * du; dkv = Y * dv; du0 = du; dv0 = dv;
       }
       float *o = dv_posed + ((size_t)n * V + v) * 3;
@@ -227,7 +241,6 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
       for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
       part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
     }
-    __syncthreads();    // sG/sP/sRed are rewritten for the next mesh
   }
 }
 

@@ -120,18 +120,22 @@ def _pose_fwd(x, num_cam, c: SMPLConstants, out=None):
     lib = _lib.load()
     B = x.shape[0]
     if out is None:
-        out = (_empty((B, KPAD), x), _empty((B, 24, 9), x), _empty((B, 24, 3), x), _empty((B, 24, 12), x),
-               _empty((B, 24, 3), x))
+        out = (None, _empty((B, 24, 9), x), _empty((B, 24, 3), x), _empty((B, 24, 12), x), _empty((B, 24, 3), x))
     coef, Rs, J, A, Jt = out
+    if coef is None:        # k-major (220, ld): the layout the blend GEMM's matrix cores read directly
+        coef = _empty((KPAD, lib.smplr_coef_ld(B)), x)
     check(lib.smplr_pose_fwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_template), ptr(c.J_dirs),
                              ptr(c.parents), ptr(coef), ptr(Rs), ptr(J), ptr(A), ptr(Jt), stream()),
           "smplr_pose_fwd")
     return coef, Rs, J, A, Jt
 
 
-def _blend_fwd(coef, c: SMPLConstants, out=None):
+def _blend_fwd(coef, c: SMPLConstants, B, out=None):
+    """coef: (220, smplr_coef_ld(B)) k-major, as _pose_fwd returns it, for B meshes."""
     lib = _lib.load()
-    B = coef.shape[0]
+    if tuple(coef.shape) != (KPAD, lib.smplr_coef_ld(B)):
+        raise RuntimeError("coef must be (%d, %d) for %d meshes, got %s"
+                           % (KPAD, lib.smplr_coef_ld(B), B, tuple(coef.shape)))
     v_posed = _empty((B, c.V, 3), coef) if out is None else out
     check(lib.smplr_blend_fwd(ptr(coef), ptr(c.blend), ptr(c.v_template), B, 3 * c.V, ptr(v_posed),
                               stream()), "smplr_blend_fwd")
@@ -271,7 +275,7 @@ class BatchSMPLFn(torch.autograd.Function):
         x = require_cuda(x, "x")
         ctx.set_materialize_grads(False)
         coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
-        v_posed = _blend_fwd(coef, consts)
+        v_posed = _blend_fwd(coef, consts, x.shape[0])
         verts, _ = _skin_fwd(v_posed, A, consts)
         ctx.consts, ctx.num_cam = consts, num_cam
         ctx.save_for_backward(x, Rs, J, A, v_posed)
@@ -482,7 +486,7 @@ class DecoderFn(torch.autograd.Function):
         lib = _lib.load()
         vs, W, B = int(vertex_sampling), int(img_wh), x.shape[0]
         V, VP = consts.V, (consts.V + vs - 1) // vs
-        coef, Rs, J = _empty((B, KPAD), x), _empty((B, 24, 9), x), _empty((B, 24, 3), x)
+        Rs, J = _empty((B, 24, 9), x), _empty((B, 24, 3), x)
         A, Jt = _empty((B, 24, 12), x), _empty((B, 24, 3), x)
         v_posed, verts, proj = _empty((B, V, 3), x), _empty((B, V, 3), x), _empty((B, VP, 3), x)
         mask = _empty((B, VP), x)
@@ -495,8 +499,8 @@ class DecoderFn(torch.autograd.Function):
 
         def run(lo, hi):
             xs = x[lo:hi]
-            _pose_fwd(xs, num_cam, consts, out=(coef[lo:hi], Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))
-            _blend_fwd(coef[lo:hi], consts, out=v_posed[lo:hi])
+            coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
+            _blend_fwd(coef, consts, hi - lo, out=v_posed[lo:hi])
             _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
                       out=(verts[lo:hi], proj[lo:hi]))
             _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,

@@ -356,7 +356,7 @@ def test_granular_backward_chain_equals_fused(smpl_model):
     B, V = 37, c.V
     x = t(make_x(B, 48, seed=91))
     coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
-    v_posed = ops._blend_fwd(coef, c)
+    v_posed = ops._blend_fwd(coef, c, x.shape[0])
     rng = np.random.default_rng(2)
     dverts, dproj, dJt = t(rng.normal(0, 1, (B, V, 3))), t(rng.normal(0, 1, (B, V, 3))), t(rng.normal(0, 1, (B, 24, 3)))
     fused = ops._smpl_bwd(x, 4, c, Rs, J, A, v_posed, dverts, dproj, dJt)
@@ -385,7 +385,7 @@ def test_sparse_and_dense_skinning_bit_identical(smpl_model):
     cd = dataclasses.replace(c, lbs_top4=None)
     x = t(make_x(9, 48, seed=95))
     coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
-    vp = ops._blend_fwd(coef, c)
+    vp = ops._blend_fwd(coef, c, x.shape[0])
     v1, p1 = ops._skin_fwd(vp, A, c, cam=x)
     v2, p2 = ops._skin_fwd(vp, A, cd, cam=x)
     assert torch.equal(v1, v2) and torch.equal(p1, p2)

@@ -1,0 +1,118 @@
+// Probe: blend_fwd tilings timed alone (hot caches): NT column tiles per wave (B loaded NT-wide per lane),
+// NB k-steps per register batch, DEPTH batches in flight ahead of the one being multiplied.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KP = 220;
+template <int N> struct VecN;
+template <> struct VecN<1> { typedef float type; };
+template <> struct VecN<2> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct VecN<3> { typedef float type __attribute__((ext_vector_type(3), aligned(4))); };
+template <> struct VecN<4> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+template <int N> __device__ __forceinline__ float vec_get(const typename VecN<N>::type &v, int t) { return v[t]; }
+template <> __device__ __forceinline__ float vec_get<1>(const float &v, int) { return v; }
+template <int N> __device__ __forceinline__ void vec_set(typename VecN<N>::type &v, int t, float x) { v[t] = x; }
+template <> __device__ __forceinline__ void vec_set<1>(float &v, int, float x) { v = x; }
+
+template <int NT, int NB, int DEPTH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k(const float *__restrict__ coef, const float *__restrict__ blend,
+                                              const float *__restrict__ vt, int B, int N3, int ldc,
+                                              float *__restrict__ out) {
+  typedef typename VecN<NT>::type bvec;
+  constexpr int NBATCH = 110 / NB;
+  static_assert(NBATCH * NB == 110, "NB must divide 110");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = (blockIdx.y * WPB + wave) * 32;
+  if (m0 >= B) return;
+  const int i = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x * 32 * NT + NT * i;
+  const int cc = c + NT <= N3 ? c : N3 - NT;
+  const float *ap = coef + (size_t)h * ldc + m0 + i;
+  const float *bp = blend + (size_t)h * N3 + cc;
+  const size_t arow = ldc, brow = N3;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float a[DEPTH + 1][NB];
+  bvec b[DEPTH + 1][NB];
+#define LOADB(slot, q)                                                                   \
+  _Pragma("unroll") for (int s2 = 0; s2 < NB; ++s2) {                                    \
+    const int kk = 2 * ((q) * NB + s2);                                                  \
+    a[slot][s2] = ap[(size_t)kk * arow];                                                 \
+    b[slot][s2] = *reinterpret_cast<const bvec *>(bp + (size_t)kk * brow);               \
+  }
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) { LOADB(q % (DEPTH + 1), q) }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < NBATCH; ++q) {
+    if (q + DEPTH < NBATCH) { LOADB((q + DEPTH) % (DEPTH + 1), q + DEPTH) }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < NB; ++s2)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % (DEPTH + 1)][s2], vec_get<NT>(b[q % (DEPTH + 1)][s2], t),
+                                                      acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float base[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) base[t] = vt[min(c + t, N3 - 1)];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int m = m0 + row;
+    if (m < B) {
+      float *o = out + (size_t)m * N3 + c;
+      if (c + NT <= N3) {
+        bvec v;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) vec_set<NT>(v, t, acc[t][r] + base[t]);
+        *reinterpret_cast<bvec *>(o) = v;
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (c + t < N3) o[t] = acc[t][r] + base[t];
+      }
+    }
+  }
+}
+template <typename F>
+static float timeit(F f, float *flush, size_t flush_n) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) f();
+  (void)hipDeviceSynchronize();
+  float tot = 0.f;
+  for (int i = 0; i < 10; ++i) {
+    if (flush) (void)hipMemsetAsync(flush, i, flush_n, 0);   // push the operands out of L2 like the other kernels of a step do
+    (void)hipEventRecord(e0);
+    f();
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    tot += ms;
+  }
+  return tot / 10 * 1e3f;
+}
+int main() {
+  const int B = 128, N3 = 20670, ldc = 128;
+  float *coef, *blend, *vt, *out, *flush;
+  const size_t flush_n = 512u << 20;
+  (void)hipMalloc(&coef, KP * ldc * 4); (void)hipMalloc(&blend, (size_t)KP * N3 * 4); (void)hipMalloc(&vt, N3 * 4);
+  (void)hipMalloc(&out, (size_t)B * N3 * 4); (void)hipMalloc(&flush, flush_n);
+  (void)hipMemset(coef, 0, KP * ldc * 4); (void)hipMemset(blend, 0, (size_t)KP * N3 * 4); (void)hipMemset(vt, 0, N3 * 4);
+#define RUN(NT, NB, DEPTH, WPB)                                                                                     \
+  {                                                                                                                 \
+    dim3 grid((N3 + 32 * NT - 1) / (32 * NT), (B / 32 + WPB - 1) / WPB);                                            \
+    auto f = [&] { hipLaunchKernelGGL((k<NT, NB, DEPTH, WPB>), grid, dim3(64 * WPB), 0, 0, coef, blend, vt, B, N3, ldc, out); }; \
+    printf("NT=%d NB=%2d DEPTH=%d WPB=%d: hot %.1f us   cold %.1f us\n", NT, NB, DEPTH, WPB, timeit(f, nullptr, 0), \
+           timeit(f, flush, flush_n));                                                                              \
+  }
+  RUN(1, 11, 2, 4)
+  RUN(3, 11, 2, 4) RUN(3, 10, 3, 4) RUN(3, 5, 6, 4) RUN(3, 10, 3, 2)
+  RUN(4, 11, 2, 4) RUN(4, 5, 6, 4)
+  return 0;
+}

@@ -13,7 +13,7 @@ B, W = int(os.environ.get("B", 128)), 48
 x = torch.tensor(bench.make_x(B, W, 1000), device=dev)
 st = torch.cuda.current_stream()
 res = bench.stage_breakdown(x, consts, pt, W)
-coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts); vp = ops._blend_fwd(coef, consts); verts, proj = ops._skin_fwd(vp, A, consts, cam=x)
+coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts); vp = ops._blend_fwd(coef, consts, x.shape[0]); verts, proj = ops._skin_fwd(vp, A, consts, cam=x)
 silh, sarg = ops._silh_fwd(proj, W)
 res["silh_fwd"] = round(bench.event_time_ms(lambda: ops._silh_fwd(proj, W), 10, st) * 1e3, 1)
 ds = torch.randn_like(silh)
