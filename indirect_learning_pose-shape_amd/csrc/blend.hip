@@ -118,22 +118,30 @@ __global__ __launch_bounds__(256) void blend_fwd_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------- backward (split-K)
-// dcoef[m][k] = sum_c dvp[m][c] * blendT[c][k].  blendT = blend transposed, rows padded to 224
-// floats, so the B operand (lanes along k) is read straight from global in MFMA layout (two
-// 128-B row segments per load) exactly like the forward; only the small A operand (32 meshes x
-// 32 columns per stage) is transposed, through a wave-private LDS tile.  The 4 waves of a block
-// split the block's column slice, so there is no block barrier in the main loop.
+// dcoef[m][o] = sum_c dvp[m][c] * blendT[c][o].  blendT = blend transposed, rows padded to 224
+// floats.  Same recipe as the forward, no LDS in the main loop:
+//   A (dvp, row-major (B, N3)): lane (i, h) reads the float4 dvp[m0+i][8g+4h .. 8g+4h+3]; MFMA t of
+//     group g contracts c = 8g + 4h + t over h (a permutation of the c order inside the sum)
+//   B (blendT (N3, 224)): lane (i, h) reads blendT[8g+4h+t][7i .. 7i+6] with a dwordx4 + a dwordx3
+//     load; accumulator u owns the outputs 7i + u
+// so a group of 8 columns costs 9 loads for 28 MFMAs, and 5 groups (45 loads, 140 MFMAs ~ 3.7 us
+// of matrix work) run ahead of the one being multiplied.  The 4 waves of a block split the block's
+// column slice and are summed in LDS in a fixed order; per-slice partials are summed in slice
+// order by pose_bwd (fused path) or blend_bwd_reduce_kernel: deterministic, no atomics.
 constexpr int BW_NT = 7;             // 7 x 32 = 224 >= 220 outputs
 constexpr int BW_NO = 224;           // blendT row stride and partial row stride
-constexpr int BW_ST = 32;            // columns per wave stage
-constexpr int BW_LD = 33;
+constexpr int BW_G = 8;              // columns per group
+constexpr int BW_DEPTH = 5;          // groups in flight ahead of the one being multiplied
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
 __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dvp,
                                                         const float *__restrict__ blendT, int B, int N3,
                                                         int cols_per_block, int nslices, int nmt,
                                                         float *__restrict__ part) {
-  __shared__ float smem[32 * BW_NO];          // 28,672 B: 4 wave tiles (4 x 32 x 33) then the reduction buffer
-  // XCD-aware map (as the forward): the nmt mesh tiles of one column slice share an XCD's L2.
+  extern __shared__ float sR[];               // 4 x [32][224] floats = 114,688 B: one tile per wave
+  // XCD-aware map: the nmt mesh tiles of one column slice (same blendT rows) share an XCD's L2.
   const int bid = blockIdx.x;
   const int group = bid / (8 * nmt), within = bid % (8 * nmt);
   const int slice = group * 8 + (within & 7), mt = within >> 3;
@@ -141,9 +149,11 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
   const int m0 = mt * 32;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
-  float *sAw = smem + wave * (BW_ST * BW_LD);
-  const int cw = cols_per_block / 4;
-  const int c_beg = slice * cols_per_block + wave * cw, c_end = c_beg + cw;
+  const int cw = cols_per_block / 4;          // multiple of BW_G
+  const int c_beg = slice * cols_per_block + wave * cw;
+  const int c_end = min(c_beg + cw, N3);
+  const int ncols = c_beg < c_end ? c_end - c_beg : 0;
+  const int ngroups = ncols / BW_G;           // full groups (wave-uniform); the matrix' ragged end is handled below
 
   f32x16 acc[BW_NT];
 #pragma unroll
@@ -151,82 +161,91 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  for (int c0 = c_beg; c0 < c_end; c0 += BW_ST) {
-    if (c0 >= N3) break;                       // wave-uniform
-    // stage A: 32 meshes x 32 columns, coalesced along c, stored [c][mesh]
-    {
-      float v[16];
-      const int cc = c0 + i;
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int m = m0 + it * 2 + h;
-        v[it] = (m < B && cc < N3) ? dvp[(size_t)m * N3 + cc] : 0.0f;
-      }
-#pragma unroll
-      for (int it = 0; it < 16; ++it) sAw[i * BW_LD + it * 2 + h] = v[it];
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    // 16 k-steps in 4 batches of 4; batch q+1's 28 B loads fly under batch q's 28 MFMAs
-    constexpr int NBB = 4;
-    float b0[NBB][BW_NT], b1[NBB][BW_NT];
-    auto load_b = [&](float (&b)[NBB][BW_NT], int s0) {
-#pragma unroll
-      for (int s2 = 0; s2 < NBB; ++s2) {
-        int cr = c0 + 2 * (s0 + s2) + h;
-        cr = cr < N3 ? cr : N3 - 1;            // a == 0 there
-        const float *brow = blendT + (size_t)cr * BW_NO + i;
-#pragma unroll
-        for (int t = 0; t < BW_NT; ++t) b[s2][t] = brow[t * 32];
-      }
-    };
-    auto mma_b = [&](const float (&b)[NBB][BW_NT], int s0) {
-      float a[NBB];
-#pragma unroll
-      for (int s2 = 0; s2 < NBB; ++s2) a[s2] = sAw[(2 * (s0 + s2) + h) * BW_LD + i];
-#pragma unroll
-      for (int s2 = 0; s2 < NBB; ++s2) {
-#pragma unroll
-        for (int t = 0; t < BW_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2][t], acc[t], 0, 0, 0);
-      }
-    };
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(b0, 0);
-    load_b(b1, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_b(b0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(b0, 8);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_b(b1, 4);
-    __builtin_amdgcn_sched_barrier(0);
-    load_b(b1, 12);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_b(b0, 8);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_b(b1, 12);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+  const int mr = min(m0 + i, B - 1);          // rows beyond B: clamped, their results are never stored
+  const float *arow = dvp + (size_t)mr * N3;
+  const float *bcol = blendT + 7 * i;
+
+  // group g of this wave: lane (i, h) covers columns c_beg + 8g + 4h .. +3
+  f32x4u a[BW_DEPTH + 1];
+  f32x4u bx[BW_DEPTH + 1][4];
+  f32x3u by[BW_DEPTH + 1][4];
+#define SMPLR_LOAD_GROUP(slot, g)                                                          \
+  {                                                                                        \
+    const int c0_ = c_beg + (g) * BW_G + 4 * h;                                            \
+    a[slot] = *reinterpret_cast<const f32x4u *>(arow + c0_);                               \
+    _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                     \
+      const float *br_ = bcol + (size_t)(c0_ + t_) * BW_NO;                                \
+      bx[slot][t_] = *reinterpret_cast<const f32x4u *>(br_);                               \
+      by[slot][t_] = *reinterpret_cast<const f32x3u *>(br_ + 4);                           \
+    }                                                                                      \
   }
-  // fixed-order reduction of the 4 waves through LDS, then one partial per (slice, mesh tile)
-  float *sR = smem;  // [32][224]
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
+#define SMPLR_MMA_GROUP(slot)                                                              \
+  _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                       \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_)                                       \
+      acc[u_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][t_], bx[slot][t_][u_], acc[u_], 0, 0, 0);         \
+    _Pragma("unroll") for (int u_ = 0; u_ < 3; ++u_)                                       \
+      acc[4 + u_] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[slot][t_], by[slot][t_][u_], acc[4 + u_], 0, 0, 0); \
+  }
+  // ring of DEPTH+1 register groups; the loop is unrolled by the ring length so slots are static
 #pragma unroll
-      for (int t = 0; t < BW_NT; ++t)
+  for (int g = 0; g < BW_DEPTH; ++g)
+    if (g < ngroups) SMPLR_LOAD_GROUP(g, g)
+  __builtin_amdgcn_sched_barrier(0);
+  for (int g0 = 0; g0 < ngroups; g0 += BW_DEPTH + 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          float *p = &sR[row * BW_NO + t * 32 + i];
-          *p = (w == 0) ? acc[t][r] : (*p + acc[t][r]);
-        }
+    for (int u = 0; u < BW_DEPTH + 1; ++u) {
+      const int g = g0 + u;
+      if (g < ngroups) {                      // wave-uniform
+        if (g + BW_DEPTH < ngroups) SMPLR_LOAD_GROUP((u + BW_DEPTH) % (BW_DEPTH + 1), g + BW_DEPTH)
+        __builtin_amdgcn_sched_barrier(0);
+        SMPLR_MMA_GROUP(u)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
+#undef SMPLR_LOAD_GROUP
+#undef SMPLR_MMA_GROUP
+  if (ncols - ngroups * BW_G > 0) {           // wave-uniform: only the wave that owns the end of the matrix
+    // (N3 = 8q + 6): clamped scalar loads, surplus A elements zeroed
+    const int c0 = c_beg + ngroups * BW_G + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = c0 + t, cl = min(c, N3 - 1);
+      const float av = (c < c_end) ? arow[cl] : 0.0f;
+      const float *br = bcol + (size_t)cl * BW_NO;
+      const f32x4u x = *reinterpret_cast<const f32x4u *>(br);
+      const f32x3u y = *reinterpret_cast<const f32x3u *>(br + 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[u], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) acc[4 + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, y[u], acc[4 + u], 0, 0, 0);
+    }
+  }
+  // the 4 waves park their tiles side by side in LDS (all at once: 4 x 28 KB), then every thread
+  // sums its elements over the waves in a fixed order and stores the block's partial coalesced;
+  // accumulator u of lane (i, h) holds output column 7i + u (stride 7: conflict-free)
+  float *mine = sR + wave * (32 * BW_NO);
+#pragma unroll
+  for (int t = 0; t < BW_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      mine[row * BW_NO + 7 * i + t] = acc[t][r];
+    }
   __syncthreads();
   float *dst = part + ((size_t)slice * nmt + mt) * (32 * BW_NO);
-  for (int e = tid; e < 32 * BW_NO; e += 256) dst[e] = sR[e];
+  for (int e = tid * 4; e < 32 * BW_NO; e += 256 * 4) {
+    const float4 s0 = *reinterpret_cast<const float4 *>(sR + e);
+    const float4 s1 = *reinterpret_cast<const float4 *>(sR + 32 * BW_NO + e);
+    const float4 s2 = *reinterpret_cast<const float4 *>(sR + 2 * 32 * BW_NO + e);
+    const float4 s3 = *reinterpret_cast<const float4 *>(sR + 3 * 32 * BW_NO + e);
+    float4 o;
+    o.x = ((s0.x + s1.x) + s2.x) + s3.x;
+    o.y = ((s0.y + s1.y) + s2.y) + s3.y;
+    o.z = ((s0.z + s1.z) + s2.z) + s3.z;
+    o.w = ((s0.w + s1.w) + s2.w) + s3.w;
+    *reinterpret_cast<float4 *>(dst + e) = o;
+  }
 }
 
 __global__ __launch_bounds__(256) void blend_bwd_reduce_kernel(const float *__restrict__ part, int B,
@@ -249,7 +268,7 @@ static void bwd_geometry(int B, int N3, int *nslices, int *cols_per_block) {
   int target = (256 + nmt - 1) / nmt;          // ~one block per CU
   if (target < 8) target = 8;
   int cpb = (N3 + target - 1) / target;
-  cpb = (cpb + 127) / 128 * 128;               // 4 waves x stages of 32 columns
+  cpb = (cpb + 4 * BW_G - 1) / (4 * BW_G) * (4 * BW_G);   // 4 waves x groups of 8 columns
   *cols_per_block = cpb;
   *nslices = (N3 + cpb - 1) / cpb;
 }
@@ -266,7 +285,14 @@ int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B
                               hipStream_t st) {
   const BlendBwdGeom g = blend_bwd_geom(B, N3);
   const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), 0, st, dv_posed, blend_t, B, N3, g.cols_per_block,
+  const size_t lds = (size_t)4 * 32 * BW_NO * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blend_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), lds, st, dv_posed, blend_t, B, N3, g.cols_per_block,
                      g.nslices, g.nmt, part);
   SMPLR_LAUNCH_CHECK("blend_bwd_kernel");
   return 0;
