@@ -66,11 +66,11 @@ struct Slot {
   float u, v, m, x;
 };
 
-__device__ __forceinline__ Slot classify(const float *__restrict__ pj, float m, int pos, int W) {
+__device__ __forceinline__ Slot classify(float u, float v, float m, int pos, int W) {
   Slot s;
   s.pos = pos;
-  s.u = pj[pos * 3];
-  s.v = pj[pos * 3 + 1];
+  s.u = u;
+  s.v = v;
   s.m = m;
   s.cls = 1;
   s.pix = 0;
@@ -96,7 +96,10 @@ __device__ __forceinline__ Slot classify(const float *__restrict__ pj, float m, 
 // VIS = true fuses compute_mask (visibility.hip's kernel, same arithmetic) in front: the z-buffer
 // over the vgrid x vgrid grid and the per-vertex flags live in LDS after the pixel counters, the
 // mask is written out (it is an output of the decoder) and classification reads the flags.
-template <bool VIS>
+// STAGE = true keeps every vertex' (u, v) in LDS as well (2 VP floats): the workgroup then makes
+// ONE round trip to global memory - its vertices (coalesced) and its part-table slots, requested
+// together at the top - and the per-slot gathers of classification become LDS reads.
+template <bool VIS, bool STAGE>
 __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict__ proj,
                                                         float *__restrict__ mask,
                                                         const int *__restrict__ part_pos,
@@ -104,34 +107,77 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
                                                         int VP, int W, int S, float4 *__restrict__ G,
                                                         int *__restrict__ goff, int *__restrict__ lstart,
                                                         uint2 *__restrict__ lrec, int vgrid, int ref_compat) {
-  extern __shared__ int s_cnt[];   // npix (+ VIS: z-buffer keys, visible flags)
+  extern __shared__ int s_cnt[];   // npix | VIS: z-buffer keys, visible flags | STAGE: u[VP], v[VP]
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
   __shared__ int s_any_empty, s_nonunit;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int npix = W * W;
   const float *pj = proj + (size_t)n * VP * 3;
   float *mk = mask + (size_t)n * VP;
-  unsigned int *vis = nullptr;
+  const int cells = VIS ? vgrid * vgrid : 0, words = VIS ? (VP + 31) / 32 : 0;
+  unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(s_cnt + ((npix + 1) & ~1));
+  unsigned int *vis = reinterpret_cast<unsigned int *>(zbuf + cells);
+  float *sU = reinterpret_cast<float *>(vis + words), *sV = sU + VP;
+
+  // ---- every global operand of the block, requested up front
+  const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
+  const int k0 = tid * ipt, k1 = min(K, k0 + ipt);
+  int pos[IPT_MAX];
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) pos[j] = (j < ipt) ? part_pos[min(k0 + j, K - 1)] : 0;
+  constexpr int VPT = 8;                        // vertices per thread and trip: 8192 per trip
+  float vu[VPT], vv[VPT], vz[VPT];
+  if (VIS || STAGE) {
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = min(tid + q * BIN_T, VP - 1);
+      vu[q] = pj[v * 3 + 0];
+      vv[q] = pj[v * 3 + 1];
+      vz[q] = VIS ? pj[v * 3 + 2] : 0.0f;
+    }
+  }
+  if (tid <= P) s_poff[tid] = part_off[tid];
+  if (tid == 0) { s_nonunit = 0; s_any_empty = 0; }
+  for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
   if (VIS) {
-    unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(s_cnt + ((npix + 1) & ~1));
-    const int cells = vgrid * vgrid, words = (VP + 31) / 32;
-    vis = reinterpret_cast<unsigned int *>(zbuf + cells);
     for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
     for (int i = tid; i < words; i += BIN_T) vis[i] = 0u;
-    if (tid == 0) s_any_empty = 0;
-    __syncthreads();
+  }
+  __syncthreads();
+  if (VIS || STAGE) {
     const float fG = (float)vgrid;
-    for (int v = tid; v < VP; v += BIN_T) {
-      const float pu = rintf(pj[v * 3 + 0]);   // round half to even, like tf.round (compute_mask.py:22)
-      const float pv = rintf(pj[v * 3 + 1]);
-      if (pu >= 0.0f && pu < fG && pv >= 0.0f && pv < fG) {
-        const int cell = (int)pv * vgrid + (int)pu;
-        const unsigned long long key = ((unsigned long long)orderable(pj[v * 3 + 2]) << 32) |
-                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)v);
-        atomicMax(&zbuf[cell], key);
+    for (int base = 0; base < VP; base += VPT * BIN_T) {
+      if (base > 0) {                           // VP > 8192: further trips (block-uniform)
+#pragma unroll
+        for (int q = 0; q < VPT; ++q) {
+          const int v = min(base + tid + q * BIN_T, VP - 1);
+          vu[q] = pj[v * 3 + 0];
+          vv[q] = pj[v * 3 + 1];
+          vz[q] = VIS ? pj[v * 3 + 2] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < VPT; ++q) {
+        const int v = base + tid + q * BIN_T;
+        if (v < VP) {
+          if (STAGE) { sU[v] = vu[q]; sV[v] = vv[q]; }
+          if (VIS) {
+            const float pu = rintf(vu[q]);      // round half to even, like tf.round (compute_mask.py:22)
+            const float pv = rintf(vv[q]);
+            if (pu >= 0.0f && pu < fG && pv >= 0.0f && pv < fG) {
+              const int cell = (int)pv * vgrid + (int)pu;
+              const unsigned long long key = ((unsigned long long)orderable(vz[q]) << 32) |
+                                             (unsigned long long)(0xFFFFFFFFu - (unsigned)v);
+              atomicMax(&zbuf[cell], key);
+            }
+          }
+        }
       }
     }
     __syncthreads();
+  }
+  bool vertex1 = false;                          // an empty cell makes vertex 1 visible (compute_mask.py:99)
+  if (VIS) {
     int empty = 0;
     for (int i = tid; i < cells; i += BIN_T) {
       const unsigned long long key = zbuf[i];
@@ -144,23 +190,17 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
     if (empty) s_any_empty = 1;   // benign same-value race
     __syncthreads();
-    if (tid == 0 && s_any_empty && ref_compat && VP > 1) atomicOr(&vis[0], 2u);   // vertex 1 (:99)
-    __syncthreads();
-    for (int v = tid; v < VP; v += BIN_T) mk[v] = ((vis[v >> 5] >> (v & 31)) & 1u) ? 1.0f : 500.0f;
+    vertex1 = s_any_empty && ref_compat && VP > 1;
+    for (int v = tid; v < VP; v += BIN_T)
+      mk[v] = (((vis[v >> 5] >> (v & 31)) & 1u) || (vertex1 && v == 1)) ? 1.0f : 500.0f;
   }
   float4 *Gn = G + (size_t)n * S;
   int *goffn = goff + (size_t)n * (P + 2);
   int *lstartn = lstart + (size_t)n * (npix + 1);
   uint2 *lrecn = lrec + (size_t)n * K;
 
-  if (tid <= P) s_poff[tid] = part_off[tid];
-  if (tid == 0) s_nonunit = 0;
-  for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
-  __syncthreads();
-  const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
-  const int k0 = tid * ipt, k1 = min(K, k0 + ipt);
-  // pass 1: classify each of this thread's slots ONCE (three dependent gathers per slot: keep the
-  // results in registers for the later passes), count
+  // pass 1: classify each of this thread's slots ONCE (results stay in registers for the later
+  // passes), count
   Slot sl[IPT_MAX];
   int gcnt = 0;
 #pragma unroll
@@ -168,9 +208,10 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     const int k = k0 + j;
     sl[j].cls = 0;
     if (j < ipt && k < k1) {
-      const int pos = part_pos[k];
-      const float m = VIS ? (((vis[pos >> 5] >> (pos & 31)) & 1u) ? 1.0f : 500.0f) : mk[pos];
-      sl[j] = classify(pj, m, pos, W);
+      const int ps = pos[j];
+      const float m = VIS ? ((((vis[ps >> 5] >> (ps & 31)) & 1u) || (vertex1 && ps == 1)) ? 1.0f : 500.0f) : mk[ps];
+      const float u = STAGE ? sU[ps] : pj[ps * 3], v = STAGE ? sV[ps] : pj[ps * 3 + 1];
+      sl[j] = classify(u, v, m, ps, W);
     }
     if (sl[j].cls == 1) {
       ++gcnt;
@@ -199,17 +240,17 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     if (tid == 0) lstartn[npix] = ltotal;
   }
   // pass 2: global prefix at part starts
-  {
-    int p = 0;
-    if (k0 < k1) {
-      int lo = 0, hi = P;        // largest p with poff[p] <= k0
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_poff[mid] <= k0) lo = mid; else hi = mid;
-      }
-      p = lo;
+  int p0 = 0;
+  if (k0 < k1) {
+    int lo = 0, hi = P;        // largest p with poff[p] <= k0
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_poff[mid] <= k0) lo = mid; else hi = mid;
     }
-    int run = gbase;
+    p0 = lo;
+  }
+  {
+    int p = p0, run = gbase;
 #pragma unroll
     for (int j = 0; j < IPT_MAX; ++j) {
       const int k = k0 + j;
@@ -221,28 +262,23 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int p = 0; p < P; ++p) {
-      s_gpad[p] = acc;
-      goffn[p] = acc;
-      acc += (s_gstart[p + 1] - s_gstart[p] + GP - 1) / GP * GP;
+  if (tid < 64) {                              // padded part offsets: one wave scan (P <= 31)
+    const int cnt = (tid < P) ? (s_gstart[tid + 1] - s_gstart[tid] + GP - 1) / GP * GP : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      const int t = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += t;
     }
-    s_gpad[P] = acc;
-    goffn[P] = acc;
+    if (tid <= P) {
+      s_gpad[tid] = inc - cnt;                 // tid == P: cnt = 0, inc = total
+      goffn[tid] = inc - cnt;
+    }
   }
   __syncthreads();
   // pass 3: placement
   {
-    int p = 0;
-    if (k0 < k1) {
-      int lo = 0, hi = P;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_poff[mid] <= k0) lo = mid; else hi = mid;
-      }
-      p = lo;
-    }
+    int p = p0;
     int run = gbase;
 #pragma unroll
     for (int j = 0; j < IPT_MAX; ++j) {
@@ -1037,20 +1073,24 @@ static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fus
   int *goff = reinterpret_cast<int *>(base + ws.goff_off);
   int *lstart = reinterpret_cast<int *>(base + ws.lstart_off);
   uint2 *lrec = reinterpret_cast<uint2 *>(base + ws.lrec_off);
-  size_t lds = (size_t)W * W * sizeof(int);
-  if (fuse_vis) {
-    lds = (size_t)((W * W + 1) & ~1) * sizeof(int) + (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
-    SMPLR_REQUIRE(lds <= 150 * 1024, "%s: pixel counters + grid + flags need %zu B of LDS (max 153600)", fn, lds);
-    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<true>), lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(seg_bin_kernel<true>, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K, VP,
-                       W, S, G, goff, lstart, lrec, grid_wh, ref_compat);
-  } else {
-    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<false>), lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(seg_bin_kernel<false>, dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos, part_off, P, K,
-                       VP, W, S, G, goff, lstart, lrec, 0, 0);
+  // LDS: pixel counters | fused mask: z-buffer keys + visible flags | staged (u, v) of every vertex
+  size_t lds = (size_t)((W * W + 1) & ~1) * sizeof(int);
+  if (fuse_vis) lds += (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
+  SMPLR_REQUIRE(lds <= 150 * 1024, "%s: pixel counters + grid + flags need %zu B of LDS (max 153600)", fn, lds);
+  const bool stage = lds + (size_t)VP * 8 <= 150 * 1024;
+  if (stage) lds += (size_t)VP * 8;
+#define SMPLR_BIN_LAUNCH(VIS_, STAGE_)                                                                        \
+  {                                                                                                           \
+    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<VIS_, STAGE_>), lds);                 \
+    if (rc) return rc;                                                                                        \
+    hipLaunchKernelGGL((seg_bin_kernel<VIS_, STAGE_>), dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos,   \
+                       part_off, P, K, VP, W, S, G, goff, lstart, lrec, fuse_vis ? grid_wh : 1, ref_compat);  \
   }
+  if (fuse_vis && stage) SMPLR_BIN_LAUNCH(true, true)
+  else if (fuse_vis) SMPLR_BIN_LAUNCH(true, false)
+  else if (stage) SMPLR_BIN_LAUNCH(false, true)
+  else SMPLR_BIN_LAUNCH(false, false)
+#undef SMPLR_BIN_LAUNCH
   SMPLR_LAUNCH_CHECK(fn);
   const int ntiles = (W * W + RT - 1) / RT;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
