@@ -175,7 +175,7 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
   }
 }
 
-constexpr int PBW = 256;   // pose backward: threads per block (one mesh)
+constexpr int PBW = 512;   // pose backward: threads per block (one mesh): one partial sum per thread
 
 __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
     const float *__restrict__ x, int x_stride, int num_cam, int B,
@@ -206,23 +206,29 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
     for (int e = tid; e < 220; e += PBW) L.dcoef[e] = dcoef[nn * SMPLR_KPAD + e];
     if (tid < 4) L.dcam[tid] = dcam ? dcam[nn * 4 + tid] : 0.0f;
   } else {
+    // 512 sums, one per thread, each with up to PB_INFLIGHT of its partials requested at once
+    // (clamped addresses, surplus terms replaced by 0): one round trip for the whole reduction.
+    // The order of the additions is the producers' slice / block order, as in the stand-alone
+    // reduce kernels.
+    constexpr int PB_INFLIGHT = 60;
     for (int e = tid; e < 512; e += PBW) {
-      if (e < 292) {                                     // skinning partials (B, nblk, 292)
-        const float *p = skin_part + (nn * nblk) * 292 + e;
-        float acc = 0.0f;
-#pragma unroll 27
-        for (int b = 0; b < nblk; ++b) acc += p[(size_t)b * 292];
-        if (e < 288) L.dA[e / 12][e % 12] = acc;
-        else L.dcam[e - 288] = want_dcam ? acc : 0.0f;
-      } else if (e - 292 < 220) {                        // blend split-K partials (ns, nmt, 32, 224)
-        const size_t mt = nn >> 5, r = nn & 31;
-        const float *p = blend_part + (mt * 32 + r) * 224 + (e - 292);
-        const size_t stride = (size_t)nmt * 32 * 224;
-        float acc = 0.0f;
-#pragma unroll 27
-        for (int s = 0; s < ns; ++s) acc += p[s * stride];
-        L.dcoef[e - 292] = acc;
+      const bool skin = e < 292;
+      const int cnt = skin ? nblk : ns;
+      const size_t mt = nn >> 5, r = nn & 31;
+      const float *p = skin ? skin_part + (nn * nblk) * 292 + e
+                            : blend_part + (mt * 32 + r) * 224 + min(e - 292, 219);
+      const size_t stride = skin ? (size_t)292 : (size_t)nmt * 32 * 224;
+      float acc = 0.0f;
+      for (int s0 = 0; s0 < cnt; s0 += PB_INFLIGHT) {
+        float v[PB_INFLIGHT];
+#pragma unroll
+        for (int u = 0; u < PB_INFLIGHT; ++u) v[u] = p[(size_t)min(s0 + u, cnt - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < PB_INFLIGHT; ++u) acc += (s0 + u < cnt) ? v[u] : 0.0f;
       }
+      if (e < 288) L.dA[e / 12][e % 12] = acc;
+      else if (e < 292) L.dcam[e - 288] = want_dcam ? acc : 0.0f;
+      else if (e - 292 < 220) L.dcoef[e - 292] = acc;
     }
   }
   __syncthreads();
