@@ -591,6 +591,63 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
   }
 }
 
+// One row strip (a 32-lane group, lane = channel) over its W pixels for one slot window.  MW =
+// false is the standard single-window case (no window test per pixel).  The arithmetic is
+// branch-free (a masked pixel contributes kk = 0); the only divergent step is the run boundary.
+template <bool MW>
+__device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, const short *__restrict__ arg,
+                                            const float4 *__restrict__ R, float *acc, size_t row0, int W, int C,
+                                            int ch, float fr, int base) {
+  const int chc = min(ch, C - 1);
+  const bool chok = ch >= 1 && ch < C;
+  int cur = -1;
+  float sx = 0.0f, sy = 0.0f;
+  for (int c0 = 0; c0 < W; c0 += SB_U) {
+    int a[SB_U];
+    float g[SB_U];
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+      const int cc = (c0 + u < W) ? c0 + u : W - 1;
+      const size_t po = row0 + cc;
+      a[u] = arg[po * 32 + ch];
+      g[u] = dseg[po * C + chc];                  // unconditional load (slots >= C are masked below)
+    }
+    float4 rv[SB_U];
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+      const int gate = __shfl(a[u], 0, 32);       // channel-0 lane of this pixel: 1 = clip passes gradient
+      const float g0 = __shfl(g[u], 0, 32);
+      g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
+      if (!(chok && c0 + u < W)) a[u] = -1;
+      if (MW) {
+        a[u] -= base;                             // another window's slot -> masked
+        if (a[u] >= SB_SLOTS) a[u] = -1;
+      }
+      rv[u] = R[base + max(a[u], 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+      const float fc = (float)(c0 + u);
+      const float du = rv[u].x - fc, dv = rv[u].y - fr;
+      const float d2 = fmaf(du, du, dv * dv);
+      const float x = fast_sqrt(d2 * rv[u].z);    // m * d, as the forward computed it
+      // d score / d(u,v) = -score * m * (p - q) / d = -score * x * (p - q) / d^2
+      const float k = -g[u] * fast_exp_neg(x) * x;
+      const bool on = a[u] >= 0 && d2 > 0.0f && k != 0.0f;
+      const float kk = on ? k * __builtin_amdgcn_rcpf(d2) : 0.0f;
+      if (on && a[u] != cur) {
+        seg_flush(acc, cur, sx, sy);
+        cur = a[u];
+        sx = 0.0f;
+        sy = 0.0f;
+      }
+      sx = fmaf(kk, du, sx);
+      sy = fmaf(kk, dv, sy);
+    }
+  }
+  seg_flush(acc, cur, sx, sy);
+}
+
 __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ dseg,
                                                       const short *__restrict__ arg,
                                                       const float4 *__restrict__ rec, int S, int VP, int W,
@@ -610,7 +667,6 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
   const int C = P + 1, npix = W * W;
   const int ch = tid & 31, strip = tid >> 5;
   const int ro = blockIdx.x * SB_ROWS + strip;            // output (flipped) row of this strip
-  const int cbeg = 0, cend = W;
   const float fr = (float)(W - 1 - ro);
   const size_t row0 = (size_t)n * npix + (size_t)ro * W;
   const int nwin = (nslots + SB_SLOTS - 1) / SB_SLOTS;    // 1 in the standard pipeline
@@ -621,52 +677,8 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
     for (int i = tid; i < nsl * 2; i += 256) acc[i] = 0.0f;
     __syncthreads();
     if (ro < W) {
-      int cur = -1;
-      float sx = 0.0f, sy = 0.0f;
-      for (int c0 = cbeg; c0 < cend; c0 += SB_U) {
-        int a[SB_U];
-        float g[SB_U];
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) {
-          const int cc = (c0 + u < cend) ? c0 + u : cend - 1;
-          const size_t po = row0 + cc;
-          a[u] = arg[po * 32 + ch];
-          g[u] = dseg[po * C + min(ch, C - 1)];       // unconditional load (slots >= C are masked below)
-        }
-        float4 rv[SB_U];
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) {
-          const int gate = __shfl(a[u], 0, 32);     // channel-0 lane of this pixel: 1 = clip passes gradient
-          const float g0 = __shfl(g[u], 0, 32);
-          g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
-          if (!(ch >= 1 && ch < C && c0 + u < cend)) a[u] = -1;
-          if (nwin > 1 && (a[u] < base || a[u] >= base + SB_SLOTS)) a[u] = -1;   // another window's slot
-          rv[u] = R[a[u] >= 0 ? a[u] : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < SB_U; ++u) {
-          if (a[u] >= 0) {
-            const float fc = (float)(c0 + u);
-            const float du = rv[u].x - fc, dv = rv[u].y - fr;
-            const float d2 = fmaf(du, du, dv * dv);
-            const float x = fast_sqrt(d2 * rv[u].z);          // m * d, as the forward computed it
-            // d score / d(u,v) = -score * m * (p - q) / d = -score * x * (p - q) / d^2
-            const float k = -g[u] * fast_exp_neg(x) * x;
-            if (d2 > 0.0f && k != 0.0f) {
-              const float kk = k / d2;
-              if (a[u] != cur) {
-                seg_flush(acc, cur - base, sx, sy);
-                cur = a[u];
-                sx = 0.0f;
-                sy = 0.0f;
-              }
-              sx = fmaf(kk, du, sx);
-              sy = fmaf(kk, dv, sy);
-            }
-          }
-        }
-      }
-      seg_flush(acc, cur - base, sx, sy);
+      if (nwin == 1) seg_bwd_row<false>(dseg, arg, R, acc, row0, W, C, ch, fr, 0);
+      else seg_bwd_row<true>(dseg, arg, R, acc, row0, W, C, ch, fr, base);
     }
     __syncthreads();
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
