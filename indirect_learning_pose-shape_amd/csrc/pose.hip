@@ -106,6 +106,9 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
   const int n = blockIdx.x * MPB + wave;
   const bool live = n < B;
   PoseLds &L = lds[wave];
+  // the kinematic tree, one entry per lane, fetched once: the chain loop below takes parent(i) with
+  // v_readlane instead of paying a scalar-load round trip per joint
+  const int par = parents[lane < 24 ? lane : 0];
   const float *xr = x + (size_t)(live ? n : 0) * x_stride;
   const float *beta = xr + num_cam + 72;
 
@@ -143,8 +146,9 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
     L.G[0][lane] = (c < 3) ? L.Rs[0][r * 3 + c] : L.J[0][r];
   }
   wave_sync();
+#pragma unroll
   for (int i = 1; i < 24; ++i) {
-    const int p = parents[i];
+    const int p = __builtin_amdgcn_readlane(par, i);
     if (live && lane < 12) {
       const int r = lane >> 2, c = lane & 3;
       float acc;
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
   }
   __syncthreads();
   if (tid >= 64) return;                                 // the rest is one wavefront's work
+  const int par = parents[lane < 24 ? lane : 0];         // parent(i) by v_readlane in the chain loop
   wave_sync();
   if (live && lane < 24) {
     const int i = lane;
@@ -249,8 +254,9 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
       L.dJ[i][c] = -(L.G[i][0 * 4 + c] * dAt[0] + L.G[i][1 * 4 + c] * dAt[1] + L.G[i][2 * 4 + c] * dAt[2]);
   }
   wave_sync();
+#pragma unroll
   for (int i = 23; i >= 1; --i) {
-    const int p = parents[i];
+    const int p = __builtin_amdgcn_readlane(par, i);
     float upd = 0.f;
     if (live && lane < 9) {
       const int r = lane / 3, c = lane % 3;
