@@ -580,3 +580,33 @@ def test_seg_backward_many_records_windows(layer, part_tables):
     (to.projects_to_seg(po, torch.tensor(mask.cpu().numpy(), dtype=torch.float64), W, ids, off)
      * torch.tensor(g.cpu().numpy(), dtype=torch.float64)).sum().backward()
     grad_close(d1.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(seg, windows)")
+
+
+# ----------------------------------------------------------------------------------- BASELINE-size batches
+def test_full_size_batch_is_row_independent(smpl_model):
+    """B = 160 (BASELINE configs[2] is 128; 160 = one full 128-mesh group + a ragged one, 5 mesh tiles
+    in the split-K backward): every op is independent per mesh, so the big batch must reproduce the
+    rows computed 32 at a time - forward bit for bit (same k order per row whatever the tiling),
+    backward to rounding (the split-K slice geometry depends on the batch) - and match the float64
+    oracle on rows picked from both mesh groups."""
+    from ilps_amd.decoder import SMPLDecoder
+    from oracle import np_oracle as o
+    W, B = 48, 160
+    x = make_x(B, W, seed=123)
+    g = np.random.default_rng(5).normal(0, 1, (B, W, W, 32)).astype(np.float32)
+    dec = SMPLDecoder(smpl_model, img_wh=W)
+    xg = t(x).requires_grad_(True)
+    out = dec(xg)
+    (out["seg"] * t(g)).sum().backward()
+    for lo in range(0, B, 32):
+        xs = t(x[lo:lo + 32]).requires_grad_(True)
+        o2 = dec(xs)
+        (o2["seg"] * t(g[lo:lo + 32])).sum().backward()
+        assert torch.equal(o2["verts"], out["verts"][lo:lo + 32]), "verts rows %d.." % lo
+        assert torch.equal(o2["mask"], out["mask"][lo:lo + 32])
+        assert torch.equal(o2["seg"], out["seg"][lo:lo + 32]), "seg rows %d.." % lo
+        grad_close(xg.grad[lo:lo + 32].cpu().numpy(), xs.grad.cpu().numpy(), 1e-4, "dx rows %d.." % lo)
+    rows = [0, 31, 127, 128, 159]
+    ref = o.smpl_layer_call(x[rows].astype(np.float64), smpl_model)
+    assert np.abs(out["verts"][rows].detach().cpu().numpy() - ref).max() <= VERT_ATOL
+    assert torch.isfinite(xg.grad).all()
