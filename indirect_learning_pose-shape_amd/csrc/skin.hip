@@ -19,7 +19,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SK_MB = 1;       // meshes per thread in the forward (weights stay in registers)
 constexpr int SKB_T = 256;     // backward block: 256 vertices (4 waves)
-constexpr int SKB_WLD = 25;    // LDS stride of a vertex' 24 weights (odd: conflict-free)
 
 // top4 (V,8): per vertex its (up to) 4 non-zero skinning weights and their joint indices (as floats),
 // or NULL.  Real SMPL rows have <= 4 non-zeros, so T = sum_j w_j A_j needs 4 x 12 FMAs, not 24 x 12;
@@ -119,7 +118,6 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   __shared__ float sG[SKB_T][4];    // g (3) per vertex
   __shared__ float sP[SKB_T][4];    // [v_posed;1]
   __shared__ float sRed[SKB_T / 64][SKB_PART];
-  __shared__ float sW[SKB_T * SKB_WLD];
   __shared__ float4 sAj[72];        // this mesh's 24 x 12 joint matrix
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int v = blockIdx.x * SKB_T + tid;
@@ -134,13 +132,27 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
   // the mesh's joint matrix, the vertex and its incoming gradients (clamped, unconditional loads:
   // a per-lane condition around a load costs a branch and a drained vmcnt each), so the block
   // pays one round trip to memory instead of three.
-  float w[24];
-  {
+  float w[SPARSE ? 1 : 24];
+  if (!SPARSE) {
     const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const float4 t = wp[q];
       w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    }
+  }
+  // A operand of the dA product, straight from the (L2-resident) weight table in MFMA layout:
+  // lane (li, lk) of step s holds w[vertex 64 wave + 4 s + lk][joint li] and [joint 16 + li]
+  // (4 rows x 64-B segments per load); 32 loads per wave, requested with everything else.
+  const int li = lane & 15, lk = lane >> 4;
+  float wa0[16], wa1[16];
+  {
+    const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
+#pragma unroll
+    for (int sI = 0; sI < 16; ++sI) {
+      const float *wr = lbs + (size_t)min(vb + 4 * sI, V - 1) * 24;      // tail rows: g = 0 there
+      wa0[sI] = wr[li];
+      wa1[sI] = wr[16 + (li & 7)];
     }
   }
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -165,12 +177,9 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     gp0 = d[0]; gp1 = d[1]; gp2 = d[2];
     ck0 = c[0]; ck1 = c[1];
   }
-#pragma unroll
-  for (int j = 0; j < 24; ++j) sW[tid * SKB_WLD + j] = w[j];
   if (tid < 72) sAj[tid] = aj;
   __syncthreads();
 
-  const int li = lane & 15, lk = lane >> 4;
   const int cr = li >> 2, cc = li & 3;   // dT component j = li = r*4+c  (valid for li < 12)
 
   {
@@ -180,10 +189,10 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
     float T[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) T[e] = 0.0f;
-#pragma unroll 4
+#pragma unroll
     for (int jq = 0; jq < (SPARSE ? 4 : 24); ++jq) {
       const int j = SPARSE ? jx[jq & 3] : jq;
-      const float wj = SPARSE ? w4[jq & 3] : sW[tid * SKB_WLD + jq];
+      const float wj = SPARSE ? w4[jq & 3] : w[SPARSE ? 0 : jq];
       const float4 r0 = sAj[j * 3], r1 = sAj[j * 3 + 1], r2 = sAj[j * 3 + 2];
       T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
       T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
@@ -212,11 +221,11 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
 
     // dA tile on the matrix cores: D[joint][comp] += sum_k w[vk][joint] * g[vk][comp>>2]*ph[vk][comp&3]
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int t = wave * 64 + s * 4 + lk;     // tail vertices carry g = 0 and finite (clamped) weights
-      const float a0 = sW[t * SKB_WLD + li];
-      const float a1 = (li < 8) ? sW[t * SKB_WLD + 16 + li] : 0.0f;
+      const float a0 = wa0[s];
+      const float a1 = (li < 8) ? wa1[s] : 0.0f;
       const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
