@@ -31,7 +31,7 @@ namespace smplr {
 
 constexpr int CH = SMPLR_CHUNK;      // 8: silhouette list padding
 static int set_lds_attr(const void *fn, size_t lds);
-constexpr int RT = 256;              // pixels (threads) per raster block
+constexpr int RT = 256;              // pixels (threads) per silhouette raster block
 constexpr float X_ZERO = 104.0f;     // expf(-x) rounds to 0 in fp32 for x >= 104
 constexpr float M_LOCAL = 208.0f;    // m > 208 => 104/m < 0.5 px: only the nearest pixel centre
 constexpr int GP = 4;                // global-list group size (padding granule)
@@ -317,9 +317,11 @@ __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
 __device__ __forceinline__ float fast_exp_neg(float x) { return __expf(-x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-constexpr int HC = 8;     // channels per wave (channel group)
-constexpr int TLD = 9;    // tile row stride
-constexpr int NG = 4;     // channel groups = waves per 64-pixel group
+constexpr int NG = 4;            // channel groups = waves per 64-pixel group (8: 55.7 us, 4: 48 us)
+constexpr int HC = 32 / NG;      // channels per wave (channel group)
+constexpr int TLD = HC + 1;      // tile row stride
+constexpr int RTS = 1024 / NG;   // pixels per segmentation raster block (block = 1024 threads)
+constexpr int WPT = RTS / 64;    // 64-pixel sub-tiles per block
 constexpr int NREC = 1024;  // records of a mesh's global list that fit the block's LDS copy (16 KB)
 
 // One vertex against this lane's pixel: strict '<' keeps the first arg-min in list order.
@@ -404,15 +406,15 @@ __device__ __forceinline__ void lds_scan(const char *base, int beg, int end, f32
 // per-wave dependent chain (scalar loads -> VALU -> exp -> LDS, part after part), so the 32 channels
 // are spread over 4 waves instead of walked by one; the background channel needs the sum over all
 // parts, exchanged through LDS (fixed order).
-__global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
+__global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
                                                              const int *__restrict__ goff,
                                                              const int *__restrict__ lstart,
                                                              const uint2 *__restrict__ lrec, int P, int K,
                                                              int S, int W, int B, int ntiles,
                                                              float *__restrict__ seg, short *__restrict__ arg) {
-  __shared__ float sS[NG * RT * TLD];
-  __shared__ short sA[NG * RT * TLD];
-  __shared__ float sSum[NG][RT];
+  __shared__ float sS[NG * RTS * TLD];
+  __shared__ short sA[NG * RTS * TLD];
+  __shared__ float sSum[NG][RTS];
   __shared__ f32x4 sRec[3 * NREC / 4];   // records, field-major: u[NREC] | v[NREC] | m^2[NREC]
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
@@ -422,10 +424,10 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   if (n >= B) return;                                    // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
-  const int g = wave >> 2, pw = wave & 3;                // channel group, pixel sub-tile
+  const int g = wave / WPT, pw = wave % WPT;             // channel group, pixel sub-tile
   const int pt = pw * 64 + lane;                         // pixel within the tile
   const int npix = W * W;
-  const int q = tile * RT + pt;
+  const int q = tile * RTS + pt;
   const int qc = q < npix ? q : npix - 1;
   const int r = qc / W, c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   // array per field, and read by its 16 waves four records at a time with broadcast ds_read_b128
   // (in-order, counted waits); longer lists use the scalar-load path below.  Both evaluate the
   // same fp32 expressions.
-  static_assert(RT * NG == NREC, "one record per thread");
+  static_assert(RTS * NG == NREC, "one record per thread");
   {
     // thread i copies record i before the list length is even known (slots beyond it hold stale
     // bytes nobody reads), so the copy shares the first round trip to memory
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   // the first two local records of this pixel are fetched now and used after the pair loop
   const uint2 lr0 = lrecn[min(l0, K - 1)], lr1 = lrecn[min(l0 + 1, K - 1)];
   const f32x2 fc2 = {fc, fc}, fr2 = {fr, fr};
-  float *myS = &sS[(g * RT + pt) * TLD];
-  short *myA = &sA[(g * RT + pt) * TLD];
+  float *myS = &sS[(g * RTS + pt) * TLD];
+  short *myA = &sA[(g * RTS + pt) * TLD];
   const int ch0 = g * HC;
 
   {
@@ -534,23 +536,26 @@ __global__ __launch_bounds__(RT * NG) void raster_fwd_kernel(const float4 *__res
   }
   __syncthreads();
   if (g == 0) {
-    const float sum = ((sSum[3][pt] + sSum[2][pt]) + sSum[1][pt]) + sSum[0][pt];
+    float sum = sSum[NG - 1][pt];
+#pragma unroll
+    for (int gg = NG - 2; gg >= 0; --gg) sum += sSum[gg][pt];
     myS[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
     myA[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): tile writes done
   __builtin_amdgcn_wave_barrier();
-  // write this wave's 64 pixels x 8 channels; lane -> (pixel, 4-channel half)
+  // write this wave's 64 pixels x HC channels; lane -> (pixel, group of 4 channels)
+  constexpr int Q4 = HC / 4;
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < Q4; ++it) {
     const int e = it * 64 + lane;
-    const int pl = pw * 64 + (e >> 1), c4 = (e & 1) * 4;
-    const int qq = tile * RT + pl;
+    const int pl = pw * 64 + e / Q4, c4 = (e % Q4) * 4;
+    const int qq = tile * RTS + pl;
     if (qq < npix && ch0 + c4 < C) {
       const int rr = qq / W, cc = qq - rr * W;
       const size_t o = ((size_t)n * W + (W - 1 - rr)) * W + cc;     // rows flipped (:68)
-      const float *ts = &sS[(g * RT + pl) * TLD + c4];
-      const short *ta = &sA[(g * RT + pl) * TLD + c4];
+      const float *ts = &sS[(g * RTS + pl) * TLD + c4];
+      const short *ta = &sA[(g * RTS + pl) * TLD + c4];
       float *so = seg + o * C + ch0 + c4;
       if (ch0 + c4 + 3 < C && (C & 3) == 0) {
         *reinterpret_cast<float4 *>(so) = make_float4(ts[0], ts[1], ts[2], ts[3]);
@@ -1104,9 +1109,9 @@ static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fus
   else SMPLR_BIN_LAUNCH(false, false)
 #undef SMPLR_BIN_LAUNCH
   SMPLR_LAUNCH_CHECK(fn);
-  const int ntiles = (W * W + RT - 1) / RT;
+  const int ntiles = (W * W + RTS - 1) / RTS;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
-  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RT * NG), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
+  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RTS * NG), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
                      seg, reinterpret_cast<short *>(arg));
   SMPLR_LAUNCH_CHECK(fn);
   return 0;
