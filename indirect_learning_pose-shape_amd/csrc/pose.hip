@@ -1,6 +1,8 @@
 // K1 pose kernels: Rodrigues + pose feature + joints-from-betas + 24-joint kinematic chain,
-// forward and backward.  One 64-lane wavefront per mesh, 4 meshes per workgroup; the chain's
-// 23 dependent 3x4 products run out of LDS with lanes = matrix elements.
+// forward and backward.  Forward: one 64-lane wavefront per mesh, 4 meshes per workgroup; the
+// chain's 23 dependent 3x4 products run out of LDS with lanes = matrix elements, parent(i) by
+// v_readlane.  Backward: a 512-thread workgroup per mesh sums the producers' partials (one sum
+// per thread, all its loads in flight), then one wavefront walks the chain backwards.
 //
 // Reference: keras_smpl/batch_smpl.py:255-276 (batch_rodrigues), :230-253 (batch_skew),
 // :122 (pose_feature), :106-115 (J from v_shaped; here J = J_template + J_dirs*beta, which is

@@ -5,26 +5,30 @@
 // exp is monotone, so that is exp(-min_v m_v d_v): a masked nearest-vertex search.
 //
 // Segmentation forward = two kernels.
-//  (1) seg_bin_kernel, one workgroup per mesh: splits the part-major vertex list by reach.
+//  (1) seg_bin_kernel, one workgroup per mesh (optionally with compute_mask's z-buffer fused in
+//      front, and the mesh's vertices staged in LDS): splits the part-major vertex list by reach.
 //      In fp32 exp(-x) == 0 for x >= 104, so a vertex with mask m only matters within
 //      104/m pixels.  m > 208 ("local": the invisible vertices, m = 500) reaches at most its
 //      nearest pixel centre -> one (pixel, part, x, vertex) record, counting-sorted by pixel.
 //      m <= 208 ("global": the visible vertices, m = 1) are compacted part-major, in table
 //      order, each part padded to a multiple of 4 with +inf sentinels, as (u, v, m^2, vertex).
-//      This drops the pair count from 2304 x 6879 to 2304 x (#visible ~ 500) per mesh without
+//      This drops the pair count from 2304 x 6879 to 2304 x (#visible ~ 570) per mesh without
 //      changing a single fp32 result.
-//  (2) raster_fwd_kernel: a lane owns one pixel, a workgroup 256 consecutive pixels of one
-//      mesh.  Global records are wave-uniform, so the pair loop reads them with scalar loads
-//      (no LDS, no vector memory) and runs on the fp32 VALU: key = m^2((u-c)^2 + (v-r)^2),
-//      min per group of 4, winning group re-evaluated once per (pixel, part) for the first
-//      arg-min; score = exp(-sqrt(key)).  The pixel's local records are then merged in.  Scores
-//      and arg-mins go through a wave-private LDS tile (16 channels at a time) so the NHWC
-//      outputs are written as contiguous 64-B / 32-B pixel segments.
+//  (2) raster_fwd_kernel: a lane owns one pixel; a workgroup = 256 consecutive pixels of one mesh
+//      x 4 channel groups (16 waves).  The mesh's global records are copied to LDS once per
+//      block (field-major) and walked four at a time with broadcast ds_read_b128; keys
+//      m^2((u-c)^2 + (v-r)^2) on the packed fp32 pipe, only the minimum of a group is tracked,
+//      and the winning group is re-evaluated once per (pixel, part) for the first arg-min;
+//      score = exp(-sqrt(key)).  The pixel's local records are then merged in.  Scores and
+//      arg-mins go through an LDS tile so the NHWC outputs are written as contiguous 32-B /
+//      16-B pixel segments.  Record lists too long for LDS use scalar loads instead.
 //
-// Backward: lanes = (pixel, channel) exactly as the NHWC tensors lie in memory (coalesced, and
-// the 32 lanes of a pixel hit 31 different parts, hence different vertices); the score is
-// recomputed from the arg-min vertex (no re-read of seg); each workgroup accumulates its pixel
-// range in LDS (V' x 2 floats, ds_add_f32) and flushes the non-zero entries with float atomics.
+// Backward (seg_bwd_kernel + seg_bwd_merge_kernel): lanes = channels of a pixel exactly as the
+// NHWC tensors lie in memory (coalesced; the 32 lanes of a pixel hit 31 different parts, hence
+// different vertices); the score is recomputed from the arg-min record (no re-read of seg);
+// runs of pixels that share an arg-min are summed in registers and reach the block's LDS slot
+// accumulators (ds_add_f32) only at run boundaries; per-block slot sums are merged in a fixed
+// order and scattered to the vertices with plain stores (no global atomics, no memset).
 #include "common.h"
 
 namespace smplr {

@@ -3,14 +3,15 @@
 //
 // Reference: keras_smpl/batch_smpl.py:135-145 (W tiled to (N,6890,24), T = W x A, v_homo =
 // T x [v_posed;1]) and keras_smpl/projection.py:54-81.  The reference materialises W (0.66 MB
-// per mesh) and T (0.44 MB per mesh); here a lane owns one vertex, keeps its 24 skinning
-// weights in registers across a group of meshes, and reads each mesh's 24x12 joint matrix
-// through wave-uniform (scalar) loads.
+// per mesh) and T (0.44 MB per mesh); here a lane owns one vertex, holds its (up to 4 non-zero,
+// else all 24) skinning weights in registers and blends the mesh's 24x12 joint matrix out of
+// LDS; every global operand of a block is requested before its first barrier.
 //
 // Backward: dv_posed = T^T g per vertex on the VALU;  dA[j] = sum_v w[v][j] * (g (x) [v_posed;1])
 // is a (24 x Vchunk) x (Vchunk x 12) product per mesh and runs on the fp32 matrix cores
-// (v_mfma_f32_16x16x4_f32, two 16-joint tiles, K = 64 vertices per wave), reduced across the
-// block's waves in LDS and across blocks by a fixed-order second kernel (no atomics).
+// (v_mfma_f32_16x16x4_f32, two 16-joint tiles, K = 64 vertices per wave; the weights operand is
+// read from the weight table directly in MFMA layout), reduced across the block's waves in LDS
+// and across blocks in a fixed order by pose_bwd / skin_bwd_reduce_kernel (no atomics).
 #include "common.h"
 
 namespace smplr {
