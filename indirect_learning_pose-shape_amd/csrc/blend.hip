@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
                                                         const float *__restrict__ blendT, int B, int N3,
                                                         int cols_per_block, int nslices, int nmt,
                                                         float *__restrict__ part) {
-  extern __shared__ float sR[];               // 4 x [32][224] floats = 114,688 B: one tile per wave
+  extern __shared__ __attribute__((aligned(16))) float sR[];   // 4 x [32][224] floats = 114,688 B: one tile per wave
   // XCD-aware map: the nmt mesh tiles of one column slice (same blendT rows) share an XCD's L2.
   const int bid = blockIdx.x;
   const int group = bid / (8 * nmt), within = bid % (8 * nmt);

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
                                                         int VP, int W, int S, float4 *__restrict__ G,
                                                         int *__restrict__ goff, int *__restrict__ lstart,
                                                         uint2 *__restrict__ lrec, int vgrid, int ref_compat) {
-  extern __shared__ int s_cnt[];   // npix | VIS: z-buffer keys, visible flags | STAGE: u[VP], v[VP]
+  // (16-B aligned: the 64-bit z-buffer keys behind the counters need 8, whatever the static LDS in front)
+  extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // npix | VIS: z-buffer keys, visible flags | STAGE: u[VP], v[VP]
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
   __shared__ int s_any_empty, s_nonunit;
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -801,7 +802,7 @@ static SilhWs silh_ws_layout(int B, int VP, int W) {
 __global__ __launch_bounds__(BIN_T) void silh_bin_kernel(const float *__restrict__ proj, int VP, int W, int ccap,
                                                          int vcap, float4 *__restrict__ CL,
                                                          float4 *__restrict__ SR, int4 *__restrict__ hdr) {
-  extern __shared__ int s_cnt[];   // GW*GW
+  extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // GW*GW
   __shared__ int s_wave[BIN_T / 64];
   __shared__ int s_nout;
   const int n = blockIdx.x, tid = threadIdx.x;
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
                                                         const int *__restrict__ arg,
                                                         const float *__restrict__ proj, int VP, int W,
                                                         float *__restrict__ dproj) {
-  extern __shared__ float acc[];
+  extern __shared__ __attribute__((aligned(16))) float acc[];
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < VP * 2; i += 1024) acc[i] = 0.0f;
   __syncthreads();

@@ -13,7 +13,7 @@ namespace smplr {
 
 __global__ __launch_bounds__(1024) void visibility_kernel(const float *__restrict__ proj, int VP, int G,
                                                           int ref_compat, float *__restrict__ mask) {
-  extern __shared__ unsigned long long zbuf[];                 // G*G keys
+  extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];                 // G*G keys
   unsigned int *vis = reinterpret_cast<unsigned int *>(zbuf + (size_t)G * G);  // ceil(VP/32) words
   __shared__ int any_empty;
   const int n = blockIdx.x, tid = threadIdx.x;
