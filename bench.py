@@ -279,6 +279,28 @@ def main():
             t_smpl = event_time_ms(smpl_only, 30, torch.cuda.current_stream())
             line["aux"] = {"batch_smpl_fwd_bwd_B256": {"meshes_per_s": round(256 / (t_smpl * 1e-3), 1),
                                                        "ms_per_step": round(t_smpl, 4), "launch": "eager"}}
+            try:                                   # the same step replayed from a HIP graph (no host launch time)
+                sg = torch.cuda.Stream()
+                sg.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(sg):
+                    smpl_only()
+                torch.cuda.current_stream().wait_stream(sg)
+                torch.cuda.synchronize()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    smpl_only()
+                for _ in range(5):
+                    g2.replay()
+                torch.cuda.synchronize()
+                t0g = time.perf_counter()
+                for _ in range(100):
+                    g2.replay()
+                torch.cuda.synchronize()
+                t_g = (time.perf_counter() - t0g) / 100 * 1e3
+                line["aux"]["batch_smpl_fwd_bwd_B256"].update(
+                    {"graph_meshes_per_s": round(256 / (t_g * 1e-3), 1), "graph_ms_per_step": round(t_g, 4)})
+            except Exception as e:
+                line["aux"]["batch_smpl_fwd_bwd_B256"]["graph_error"] = str(e)
             # loss head: softmax + focal loss on the (B,W,W,32) scores, HBM-bound.
             # algorithmic bytes: fwd = scores 128 + label 4 + loss 4 B/pixel; bwd = 128 + 4 + 4 + 128 B/pixel
             seg_s = torch.rand(B, W, W, 32, device=dev)
