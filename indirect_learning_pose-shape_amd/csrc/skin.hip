@@ -111,7 +111,7 @@ constexpr int SKB_PART = 292;
 constexpr int SKB_MB = 1;
 
 template <bool SPARSE>
-__global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
+__global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) void skin_bwd_kernel(
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
     const float *__restrict__ lbs, const float *__restrict__ top4, const float *__restrict__ A,
     const float *__restrict__ cam,
@@ -142,20 +142,7 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
       w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
     }
   }
-  // A operand of the dA product, straight from the (L2-resident) weight table in MFMA layout:
-  // lane (li, lk) of step s holds w[vertex 64 wave + 4 s + lk][joint li] and [joint 16 + li]
-  // (4 rows x 64-B segments per load); 32 loads per wave, requested with everything else.
   const int li = lane & 15, lk = lane >> 4;
-  float wa0[16], wa1[16];
-  {
-    const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
-#pragma unroll
-    for (int sI = 0; sI < 16; ++sI) {
-      const float *wr = lbs + (size_t)min(vb + 4 * sI, V - 1) * 24;      // tail rows: g = 0 there
-      wa0[sI] = wr[li];
-      wa1[sI] = wr[16 + (li & 7)];
-    }
-  }
   float w4[4] = {0.f, 0.f, 0.f, 0.f};
   int jx[4] = {0, 0, 0, 0};
   if (SPARSE) {
@@ -215,6 +202,20 @@ __global__ __launch_bounds__(SKB_T) void skin_bwd_kernel(
       o[0] = T[0] * g0 + T[4] * g1 + T[8] * g2;
       o[1] = T[1] * g0 + T[5] * g1 + T[9] * g2;
       o[2] = T[2] * g0 + T[6] * g1 + T[10] * g2;
+    }
+    // A operand of the dA product, straight from the (L2-resident) weight table in MFMA layout:
+    // lane (li, lk) of step s holds w[vertex 64 wave + 4 s + lk][joint li] and [joint 16 + li]
+    // (4 rows x 64-B segments per load); 32 loads per wave, requested once T is done (their latency
+    // overlaps the barrier; asked for at the top they cost 32 live registers = one wave per SIMD).
+    float wa0[16], wa1[16];
+    {
+      const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
+  #pragma unroll
+      for (int sI = 0; sI < 16; ++sI) {
+        const float *wr = lbs + (size_t)min(vb + 4 * sI, V - 1) * 24;      // tail rows: g = 0 there
+        wa0[sI] = wr[li];
+        wa1[sI] = wr[16 + (li & 7)];
+      }
     }
     sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
     sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
