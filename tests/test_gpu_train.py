@@ -49,3 +49,25 @@ def test_build_model_handles(smpl_model):
         raw = sm.to(dev).eval()(img)
     assert raw.shape == (2, 48, 48, 32)
     assert torch.allclose(torch.softmax(raw.reshape(2, -1, 32), -1), s, atol=1e-5)
+
+
+def test_predict_batch_of_one(smpl_model):
+    """BASELINE configs[0] shape: one 48x48 prediction (encoder on stock torch, decoder on the HIP path);
+    the decoder part is checked against the oracle on the regressed parameters."""
+    import numpy as np
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.inference import predict_batch
+    from ilps_amd.model import SMPLRegressor
+    from oracle import np_oracle as o
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    reg = SMPLRegressor(48, "enet", True).to(dev)
+    dec = SMPLDecoder(smpl_model, img_wh=48)
+    img = torch.rand(1, 3, 256, 256, device=dev)
+    out = predict_batch(reg, dec, img)
+    assert out["verts"].shape == (1, 6890, 3) and out["segs"].shape == (1, 48, 48, 32)
+    assert out["seg_maps"].shape == (1, 48, 48) and out["seg_maps"].dtype == torch.int64
+    x = out["smpl"].cpu().numpy().astype(np.float64)
+    ref = o.smpl_layer_call(x, smpl_model)
+    assert np.abs(out["verts"].cpu().numpy() - ref).max() <= 1e-4
+    assert torch.equal(out["seg_maps"], out["segs"].argmax(-1))
