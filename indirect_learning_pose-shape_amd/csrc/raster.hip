@@ -703,8 +703,8 @@ __global__ __launch_bounds__(256) void seg_bwd_merge_kernel(const float *__restr
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
   for (int slot = blockIdx.x * 256 + threadIdx.x; slot < nslots; slot += SB_SLOTS) {
+    // the record and the partials are requested together (one round trip); the sentinel test comes after
     const int v = __float_as_int(R[slot].w);
-    if (v < 0) continue;                                     // padding sentinel
     const int win = slot / SB_SLOTS;
     const float *p = part + ((size_t)n * nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (slot - win * SB_SLOTS) * 2;
     float sx = 0.0f, sy = 0.0f;
@@ -713,9 +713,11 @@ __global__ __launch_bounds__(256) void seg_bwd_merge_kernel(const float *__restr
       sx += t.x;
       sy += t.y;
     }
-    float *o = dproj + ((size_t)n * VP + v) * 3;
-    o[0] = sx;
-    o[1] = sy;
+    if (v >= 0) {                                            // v < 0: padding sentinel
+      float *o = dproj + ((size_t)n * VP + v) * 3;
+      o[0] = sx;
+      o[1] = sy;
+    }
   }
 }
 
