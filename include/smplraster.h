@@ -196,6 +196,15 @@ int smplr_focal_bwd(const float *logits, const int32_t *labels, const float *y_t
                     const float *class_w, float gamma, const float *dloss, long long npix, int C,
                     float *dlogits, void *stream);
 
+/* ---- PReLU of the ENet encoder: encoders/encoder_enet_simple.py:21,37,50,58,79 */
+/* Per-channel slope, NCHW fp32: y = x > 0 ? x : w[c] * x over x (N, C, HW).
+ * bwd: gx = x > 0 ? gy : w[c] * gy;  gw[c] = sum over n, hw of (x > 0 ? 0 : gy * x), summed in a
+ * fixed order through smplr_prelu_bwd_workspace(N,C,HW) bytes of partials (no atomics).          */
+int smplr_prelu_fwd(const float *x, const float *w, long long N, int C, int HW, float *y, void *stream);
+size_t smplr_prelu_bwd_workspace(long long N, int C, int HW);
+int smplr_prelu_bwd(const float *x, const float *w, const float *gy, long long N, int C, int HW,
+                    float *gx, float *gw, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

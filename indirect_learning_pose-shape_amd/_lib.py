@@ -50,6 +50,9 @@ SIGNATURES = {
     "smplr_silh_bwd": (c_int, [P, P, P, P, I, I, I, P, P]),
     "smplr_focal_fwd": (c_int, [P, P, P, P, c_float, c_longlong, I, P, P, P]),
     "smplr_focal_bwd": (c_int, [P, P, P, P, c_float, P, c_longlong, I, P, P]),
+    "smplr_prelu_fwd": (c_int, [P, P, c_longlong, I, I, P, P]),
+    "smplr_prelu_bwd_workspace": (c_size_t, [c_longlong, I, I]),
+    "smplr_prelu_bwd": (c_int, [P, P, P, c_longlong, I, I, P, P, P, P]),
 }
 
 _lib = None

@@ -19,6 +19,18 @@ from .keras_smpl.concat_mean_param import concat_mean_param
 from .keras_smpl.set_cam_params import load_mean_set_cam_params
 
 
+class PReLU(nn.PReLU):
+    """`PReLU(shared_axes=[1, 2])` (encoders/encoder_enet_simple.py:21): same parameters and state dict as
+    `nn.PReLU(C)`; on a HIP device the forward / backward are the package's kernels (the stock backward is
+    half of the train step: it materialises a per-element slope gradient before reducing it)."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and self.weight.numel() == x.shape[1]:
+            from . import ops
+            return ops.PReLUFn.apply(x.contiguous(), self.weight)
+        return super().forward(x)
+
+
 def _bn(ch, keras_momentum=0.99):
     # Keras `momentum` is the decay of the moving average; torch's is its complement. eps = 1e-3.
     return nn.BatchNorm2d(ch, eps=1e-3, momentum=1.0 - keras_momentum)
@@ -34,7 +46,7 @@ class _Bottleneck(nn.Module):
         st = 2 if downsample else 1
         self.downsample, self.pad_ch = downsample, cout - cin
         self.reduce = nn.Sequential(nn.Conv2d(cin, internal, st, st, bias=False), _bn(internal, 0.1),
-                                    nn.PReLU(internal))
+                                    PReLU(internal))
         if asymmetric:
             a = asymmetric
             conv = nn.Sequential(nn.Conv2d(internal, internal, (1, a), padding=(0, a // 2), bias=False),
@@ -43,10 +55,10 @@ class _Bottleneck(nn.Module):
             conv = nn.Conv2d(internal, internal, 3, padding=dilated, dilation=dilated)
         else:
             conv = nn.Conv2d(internal, internal, 3, padding=1)
-        self.conv = nn.Sequential(conv, _bn(internal, 0.1), nn.PReLU(internal))
+        self.conv = nn.Sequential(conv, _bn(internal, 0.1), PReLU(internal))
         self.expand = nn.Sequential(nn.Conv2d(internal, cout, 1, bias=False), _bn(cout, 0.1),
                                     nn.Dropout2d(dropout_rate))
-        self.act = nn.PReLU(cout)
+        self.act = PReLU(cout)
 
     def forward(self, x):
         y = self.expand(self.conv(self.reduce(x)))
@@ -64,7 +76,7 @@ class ENetEncoder(nn.Module):
     def __init__(self, dropout_rate=0.01):
         super().__init__()
         self.init_conv = nn.Conv2d(3, 13, 3, stride=2, padding=1)            # initial block (:10-14)
-        self.init_bn, self.init_act = _bn(16, 0.1), nn.PReLU(16)
+        self.init_bn, self.init_act = _bn(16, 0.1), PReLU(16)
         blocks = [_Bottleneck(16, 64, downsample=True, dropout_rate=dropout_rate)]
         blocks += [_Bottleneck(64, 64, dropout_rate=dropout_rate) for _ in range(4)]
         blocks += [_Bottleneck(64, 128, downsample=True)]

@@ -426,6 +426,37 @@ def softmax_probs(scores):
     return probs.reshape(scores.shape[0], -1, C)
 
 
+class PReLUFn(torch.autograd.Function):
+    """Per-channel PReLU on NCHW fp32 (the ENet encoder's activation, encoders/encoder_enet_simple.py:21):
+    smplr_prelu_fwd / smplr_prelu_bwd.  x (N, C, ...) and weight (C,)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = require_cuda(x, "x")
+        weight = require_cuda(weight, "weight")
+        N, C = x.shape[0], x.shape[1]
+        if weight.numel() != C:
+            raise RuntimeError("PReLU weight has %d entries for %d channels" % (weight.numel(), C))
+        HW = x.numel() // (N * C) if N * C else 1
+        y = torch.empty_like(x)
+        check(_lib.load().smplr_prelu_fwd(ptr(x), ptr(weight), N, C, HW, ptr(y), stream()), "smplr_prelu_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.dims = (N, C, HW)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        N, C, HW = ctx.dims
+        gy = require_cuda(gy, "gy")
+        lib = _lib.load()
+        gx, gw = torch.empty_like(x), torch.empty_like(weight)
+        ws = _workspace(lib.smplr_prelu_bwd_workspace(N, C, HW), x)
+        check(lib.smplr_prelu_bwd(ptr(x), ptr(weight), ptr(gy), N, C, HW, ptr(gx), ptr(gw), ptr(ws), stream()),
+              "smplr_prelu_bwd")
+        return gx, gw
+
+
 _side_streams = {}
 
 

@@ -71,3 +71,23 @@ def test_predict_batch_of_one(smpl_model):
     ref = o.smpl_layer_call(x, smpl_model)
     assert np.abs(out["verts"].cpu().numpy() - ref).max() <= 1e-4
     assert torch.equal(out["seg_maps"], out["segs"].argmax(-1))
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 128, 128), (2, 5, 7, 9), (4, 64, 1, 1), (1, 3, 70, 70)])
+def test_prelu_kernels_match_torch(shape):
+    """smplr_prelu_fwd/bwd against torch's own PReLU (fp64 on CPU): values, input gradient, slope gradient."""
+    from ilps_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    w = torch.rand(shape[1], generator=g) * 0.5 - 0.1
+    gy = torch.randn(*shape, generator=g)
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = ops.PReLUFn.apply(xd, wd)
+    y.backward(gy.to(dev))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = torch.nn.functional.prelu(x64, w64)
+    y64.backward(gy.double())
+    assert torch.allclose(y.detach().cpu().double(), y64.detach(), rtol=1e-6, atol=1e-7)
+    assert torch.allclose(xd.grad.cpu().double(), x64.grad, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(wd.grad.cpu().double(), w64.grad, rtol=1e-4, atol=1e-4)

@@ -80,6 +80,77 @@ __global__ __launch_bounds__(64 * WPB) void k(const float *__restrict__ coef, co
     }
   }
 }
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+// 16x16x4 tiles: wave = 16 meshes x 96 columns (6 accumulators of 4 registers); block = WPB waves = WPB mesh tiles
+template <int NB, int DEPTH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k16(const float *__restrict__ coef, const float *__restrict__ blend,
+                                                const float *__restrict__ vt, int B, int N3, int ldc,
+                                                float *__restrict__ out) {
+  constexpr int NBATCH = 55 / NB;
+  static_assert(NBATCH * NB == 55, "NB must divide 55");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = (blockIdx.y * WPB + wave) * 16;
+  if (m0 >= B) return;
+  const int li = lane & 15, lk = lane >> 4;
+  const int c = blockIdx.x * 96 + 6 * li;
+  const int cc = c + 6 <= N3 ? c : N3 - 6;
+  const float *ap = coef + (size_t)lk * ldc + m0 + li;
+  const float *bp = blend + (size_t)lk * N3 + cc;
+  const size_t arow = ldc, brow = N3;
+  f32x4a acc[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) acc[t] = (f32x4a){0.f, 0.f, 0.f, 0.f};
+  float a[DEPTH + 1][NB];
+  f32x4u bx[DEPTH + 1][NB];
+  f32x2u by[DEPTH + 1][NB];
+#define LOADB16(slot, q)                                                                 \
+  _Pragma("unroll") for (int s2 = 0; s2 < NB; ++s2) {                                    \
+    const int kk = 4 * ((q) * NB + s2);                                                  \
+    a[slot][s2] = ap[(size_t)kk * arow];                                                 \
+    bx[slot][s2] = *reinterpret_cast<const f32x4u *>(bp + (size_t)kk * brow);            \
+    by[slot][s2] = *reinterpret_cast<const f32x2u *>(bp + (size_t)kk * brow + 4);        \
+  }
+#pragma unroll
+  for (int q = 0; q < DEPTH; ++q) { LOADB16(q % (DEPTH + 1), q) }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < NBATCH; ++q) {
+    if (q + DEPTH < NBATCH) { LOADB16((q + DEPTH) % (DEPTH + 1), q + DEPTH) }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < NB; ++s2) {
+      const int sl = q % (DEPTH + 1);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sl][s2], bx[sl][s2][t], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[4 + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sl][s2], by[sl][s2][t], acc[4 + t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (c + 6 <= N3) {
+    float base[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) base[t] = vt[c + t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * lk + r;
+      if (m < B) {
+        float *o = out + (size_t)m * N3 + c;
+        f32x4u v4; f32x2u v2;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v4[t] = acc[t][r] + base[t];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) v2[t] = acc[4 + t][r] + base[4 + t];
+        *reinterpret_cast<f32x4u *>(o) = v4;
+        *reinterpret_cast<f32x2u *>(o + 4) = v2;
+      }
+    }
+  }
+}
+
 template <typename F>
 static float timeit(F f, float *flush, size_t flush_n) {
   hipEvent_t e0, e1;
@@ -111,8 +182,14 @@ int main() {
     printf("NT=%d NB=%2d DEPTH=%d WPB=%d: hot %.1f us   cold %.1f us\n", NT, NB, DEPTH, WPB, timeit(f, nullptr, 0), \
            timeit(f, flush, flush_n));                                                                              \
   }
-  RUN(1, 11, 2, 4)
-  RUN(3, 11, 2, 4) RUN(3, 10, 3, 4) RUN(3, 5, 6, 4) RUN(3, 10, 3, 2)
-  RUN(4, 11, 2, 4) RUN(4, 5, 6, 4)
+  RUN(3, 5, 6, 4)
+#define RUN16(NB, DEPTH, WPB)                                                                                       \
+  {                                                                                                                 \
+    dim3 grid((N3 + 95) / 96, (B / 16 + WPB - 1) / WPB);                                                            \
+    auto f = [&] { hipLaunchKernelGGL((k16<NB, DEPTH, WPB>), grid, dim3(64 * WPB), 0, 0, coef, blend, vt, B, N3, ldc, out); }; \
+    printf("16x16x4 NB=%2d DEPTH=%d WPB=%d: hot %.1f us   cold %.1f us\n", NB, DEPTH, WPB, timeit(f, nullptr, 0),  \
+           timeit(f, flush, flush_n));                                                                              \
+  }
+  RUN16(5, 3, 8) RUN16(5, 4, 8) RUN16(11, 1, 8) RUN16(5, 3, 4) RUN16(5, 4, 4) RUN16(1, 19, 8)
   return 0;
 }
