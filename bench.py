@@ -136,6 +136,25 @@ def cpu_baseline(model, W, budget_s=20.0):
                       "installable here)" % (n, Bc, W, el)}
 
 
+def parity_sample(model, consts, pt, W, dev, Bp=2):
+    """The other half of BASELINE's metric ("vert Linf vs ref"): the HIP path against the float64 oracle on Bp
+    seeded meshes - vertex L-inf, and the largest |seg - ref| / (1e-3 |ref| + 1e-6) (<= 1 passes the bar)."""
+    from oracle import np_oracle as no
+    xs = make_x(Bp, W, 4242)
+    x = torch.tensor(xs, device=dev)
+    verts, proj, mask, seg, _silh, _jt = ops.DecoderFn.apply(x, consts, 4, W, 1, pt, 64, True, False, 1)
+    ref_v = no.smpl_layer_call(xs.astype(np.float64), model)
+    pj = proj.cpu().numpy().astype(np.float64)
+    ref_m = no.compute_mask(pj)
+    ids, off = load_part_tables(1)
+    ref_s = no.projects_to_seg(pj, ref_m, W, ids, off)
+    got_s = seg.cpu().numpy()
+    return {"meshes": Bp, "vert_linf": float(np.abs(verts.cpu().numpy() - ref_v).max()), "vert_bar": 1e-4,
+            "mask_equal": bool(np.array_equal(ref_m, mask.cpu().numpy())),
+            "seg_err_over_bar": float((np.abs(got_s - ref_s) / (1e-3 * np.abs(ref_s) + 1e-6)).max()),
+            "seg_bar": "|d| <= 1e-3 |ref| + 1e-6", "oracle": "oracle/np_oracle.py (float64)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,6 +353,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(model, W)
             except Exception as e:
                 line["cpu_baseline"] = {"error": str(e)}
+            try:
+                line["parity"] = parity_sample(model, consts, pt, W, dev)
+            except Exception as e:
+                line["parity"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()
