@@ -610,3 +610,31 @@ def test_full_size_batch_is_row_independent(smpl_model):
     ref = o.smpl_layer_call(x[rows].astype(np.float64), smpl_model)
     assert np.abs(out["verts"][rows].detach().cpu().numpy() - ref).max() <= VERT_ATOL
     assert torch.isfinite(xg.grad).all()
+
+
+def test_full_size_step_is_repeatable_and_linear(smpl_model):
+    """B = 128 (BASELINE configs[2]): two runs of the same step give bit-identical forward outputs and
+    gradients equal to rounding (the only order-dependent sums are LDS accumulations inside a block);
+    the backward is linear in the cotangent: dx(a g1 + b g2) = a dx(g1) + b dx(g2)."""
+    from ilps_amd.decoder import SMPLDecoder
+    W, B = 48, 128
+    x = t(make_x(B, W, seed=777))
+    rng = np.random.default_rng(11)
+    g1, g2 = t(rng.normal(0, 1, (B, W, W, 32))), t(rng.normal(0, 1, (B, W, W, 32)))
+    dec = SMPLDecoder(smpl_model, img_wh=W)
+
+    def run(g):
+        xg = x.clone().requires_grad_(True)
+        out = dec(xg)
+        out["seg"].backward(g)
+        return out, xg.grad
+
+    o1, d1 = run(g1)
+    o2, d1b = run(g1)
+    for k in ("verts", "projects", "mask", "seg"):
+        assert torch.equal(o1[k], o2[k]), k
+    grad_close(d1b.cpu().numpy(), d1.cpu().numpy(), 1e-5, "dx repeat")
+    _, d2 = run(g2)
+    _, d12 = run(0.5 * g1 - 2.0 * g2)
+    grad_close(d12.cpu().numpy(), (0.5 * d1 - 2.0 * d2).cpu().numpy(), 1e-4, "dx linearity")
+    assert torch.isfinite(d12).all()
