@@ -772,62 +772,110 @@ __global__ __launch_bounds__(RT) void silh_fwd_kernel(const float4 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pruned silhouette forward (exact).  Vertices are binned into 1-px cells (cell = rounded position,
-// on a window of the image plus SM px of margin; the rest are "outliers", always evaluated).  A
-// vertex lies within 0.7072 px of its cell centre, so if the nearest OCCUPIED cell centre is at
-// distance Dmin from a pixel, the nearest vertex is no farther than Dmin + 0.7072 and therefore
-// lives in a cell whose centre is within T = Dmin + 1.4143 of the pixel: pass 1 finds Dmin over the
-// ~650 occupied cells, pass 2 evaluates exactly only the vertices of cells within T.  Ties are
-// broken towards the lowest vertex index, as the dense formulation's arg-max does.
+// Pruned silhouette forward (exact): one workgroup per mesh, everything in LDS, four lanes per pixel.
+// Vertices are binned into 1-px cells (cell = rounded position, on a window of the image plus SM px
+// of margin; the rest are "outliers", always evaluated) and kept in LDS sorted by cell.  For a pixel:
+//  (1) the nearest OCCUPIED cell centre, by an exact distance transform of the occupancy grid: per
+//      cell row the nearest occupied column comes from the row's occupancy bits (clz / ctz), then
+//      the minimum over the rows;
+//  (2) the vertices of that cell give a real distance d1 (<= Dmin + 0.7072: a vertex lies within
+//      0.7072 px of its cell centre);
+//  (3) any closer vertex lives in a cell whose centre is within R = d1 + 0.7072 of the pixel, so
+//      only the occupied cells inside that disc are evaluated: the set bits of each row's mask
+//      within the disc's chord (9 cells of ~10 vertices inside the body, a thin arc outside it).
+// The four lanes of a pixel take every fourth row in (1) and (3) and every fourth vertex in (2),
+// then reduce with two xor-shuffles; 16 neighbouring pixels (a 4 x 4 tile) share a wave, so its
+// lanes walk similar rows.  The earlier version scanned ALL occupied cells per wave with scalar
+// loads from global memory (any lane's candidate was everybody's work, and every record group cost
+// an L2 round trip): 57 + 212 us at B = 128.  Ties go to the lowest vertex index, as the dense
+// formulation's arg-max does (keys are packed (d^2 bits, index) and compared as 64-bit integers).
 constexpr int SM = 8;            // margin of the cell window around the image
-constexpr int SILH_WMAX = 96;    // (W + 16)^2 counters must fit LDS next to the scan scratch
+constexpr int SILH_WMAX = 96;    // (W + 16)^2 cell offsets + the vertex records must fit LDS
+constexpr int SF_T = 1024;
 
-struct SilhWs {
-  size_t cl_off, sr_off, hdr_off, total;
-  int ccap, vcap;
-};
-static SilhWs silh_ws_layout(int B, int VP, int W) {
-  SilhWs w;
+static size_t silh_fused_lds(int VP, int W) {
   const int GW = W + 2 * SM;
-  w.ccap = ((GW * GW < VP ? GW * GW : VP) + 2 * GP + 3) / 4 * 4;   // occupied cells + padding + a spare sentinel group
-  // every occupied cell's vertex list is padded to a multiple of GP records, + one spare group
-  w.vcap = (VP + (GP - 1) * (GW * GW < VP ? GW * GW : VP) + 2 * GP + 3) / 4 * 4;
-  size_t off = 0;
-  auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  w.cl_off = take((size_t)B * w.ccap * sizeof(float4));
-  w.sr_off = take((size_t)B * w.vcap * sizeof(float4));
-  w.hdr_off = take((size_t)B * sizeof(int4));
-  w.total = off;
-  return w;
+  return (size_t)((GW * GW + 2) & ~1) * 4 + (size_t)2 * GW * 8 + (size_t)VP * 12;
 }
 
-__global__ __launch_bounds__(BIN_T) void silh_bin_kernel(const float *__restrict__ proj, int VP, int W, int ccap,
-                                                         int vcap, float4 *__restrict__ CL,
-                                                         float4 *__restrict__ SR, int4 *__restrict__ hdr) {
-  extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // GW*GW
-  __shared__ int s_wave[BIN_T / 64];
+// distance (in columns) from cx to the nearest set bit of a 128-bit row mask; 1 << 20 if the row is empty
+__device__ __forceinline__ int nearest_bit(unsigned long long m0, unsigned long long m1, int cx) {
+  int dl = 1 << 20, dr = 1 << 20;
+  {
+    unsigned long long lo = m0, hi = m1;                 // bits <= cx
+    if (cx < 63) { lo &= (2ull << cx) - 1ull; hi = 0ull; }
+    else if (cx == 63) hi = 0ull;
+    else if (cx < 127) hi &= (2ull << (cx - 64)) - 1ull;
+    if (hi) dl = cx - (127 - __clzll((long long)hi));
+    else if (lo) dl = cx - (63 - __clzll((long long)lo));
+  }
+  {
+    unsigned long long lo = m0, hi = m1;                 // bits >= cx
+    if (cx < 64) lo &= ~((1ull << cx) - 1ull);
+    else { lo = 0ull; hi &= ~((1ull << (cx - 64)) - 1ull); }
+    if (lo) dr = (__ffsll((long long)lo) - 1) - cx;
+    else if (hi) dr = 64 + (__ffsll((long long)hi) - 1) - cx;
+  }
+  return dl <= dr ? -dl : dr;                            // signed offset to the nearest occupied column
+}
+
+// the same for a row of at most 64 cells
+__device__ __forceinline__ int nearest_bit1(unsigned long long m, int cx) {
+  const unsigned long long le = m & ((cx < 63) ? ((2ull << cx) - 1ull) : ~0ull);   // bits <= cx
+  const unsigned long long ge = m & ~((1ull << cx) - 1ull);                          // bits >= cx
+  const int dl = le ? cx - (63 - __clzll((long long)le)) : (1 << 20);
+  const int dr = ge ? (__ffsll((long long)ge) - 1) - cx : (1 << 20);
+  return dl <= dr ? -dl : dr;
+}
+
+__device__ __forceinline__ unsigned long long quad_min(unsigned long long k) {
+#pragma unroll
+  for (int o = 1; o <= 2; o <<= 1) {
+    const unsigned int lo = __shfl_xor((unsigned int)k, o, 64), hi = __shfl_xor((unsigned int)(k >> 32), o, 64);
+    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+    k = other < k ? other : k;
+  }
+  return k;
+}
+
+template <bool ONEWORD>   // ONEWORD: the cell window is at most 64 wide (W <= 48): one mask word per row
+__global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restrict__ proj, int VP, int W,
+                                                          float *__restrict__ out, int *__restrict__ arg_out) {
+  // 16-B aligned: the 64-bit row masks behind the counters need 8, whatever the static LDS in front
+  extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // cells (+2, even) | row masks | u[VP] | v[VP] | index[VP]
+  __shared__ int s_wave[SF_T / 64];
   __shared__ int s_nout;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int GW = W + 2 * SM, cells = GW * GW;
+  // gridDim.y workgroups share a mesh (each bins it for itself and takes every gridDim.y-th tile):
+  // with fewer meshes than CUs the pixel phase, not the binning, is what there is to spread
+  unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(s_cnt + ((cells + 2) & ~1));
+  float *sU = reinterpret_cast<float *>(rowmask + 2 * GW), *sV = sU + VP;
+  int *sI = reinterpret_cast<int *>(sV + VP);
   const float *pj = proj + (size_t)n * VP * 3;
-  float4 *CLn = CL + (size_t)n * ccap;
-  float4 *SRn = SR + (size_t)n * vcap;
-  for (int i = tid; i < cells; i += BIN_T) s_cnt[i] = 0;
+  // ---- binning: every vertex requested up front
+  float pu[IPT_MAX], pv[IPT_MAX];
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int v = min(tid + j * SF_T, VP - 1);
+    pu[j] = pj[v * 3];
+    pv[j] = pj[v * 3 + 1];
+  }
+  for (int i = tid; i < cells; i += SF_T) s_cnt[i] = 0;
+  for (int i = tid; i < 2 * GW; i += SF_T) rowmask[i] = 0ull;
   if (tid == 0) s_nout = 0;
   __syncthreads();
-  float pu[IPT_MAX], pv[IPT_MAX];
   int pc[IPT_MAX];
 #pragma unroll
   for (int j = 0; j < IPT_MAX; ++j) {
-    const int v = tid + j * BIN_T;
+    const int v = tid + j * SF_T;
     pc[j] = -2;                                  // no vertex
     if (v < VP) {
-      pu[j] = pj[v * 3];
-      pv[j] = pj[v * 3 + 1];
       const float cx = rintf(pu[j]) + (float)SM, cy = rintf(pv[j]) + (float)SM;
       if (cx >= 0.0f && cx < (float)GW && cy >= 0.0f && cy < (float)GW) {
         pc[j] = (int)cy * GW + (int)cx;
         atomicAdd(&s_cnt[pc[j]], 1);
+        atomicOr(&rowmask[2 * (int)cy + ((int)cx >> 6)], 1ull << ((int)cx & 63));
       } else {
         pc[j] = -1;                              // outlier (also NaN positions)
         atomicAdd(&s_nout, 1);
@@ -835,173 +883,128 @@ __global__ __launch_bounds__(BIN_T) void silh_bin_kernel(const float *__restrict
     }
   }
   __syncthreads();
-  // per cell: start offset (exclusive scan of counts) and index among the occupied cells
-  const int ept = (cells + BIN_T - 1) / BIN_T;
+  // exclusive scan of the counts -> placement cursors; after placement s_cnt[e] = end of cell e
+  // (= start of cell e + 1), so one array serves as both
+  const int ept = (cells + SF_T - 1) / SF_T;
   const int e0 = tid * ept, e1 = min(cells, e0 + ept);
-  int lc = 0, lo = 0;
-  for (int e = e0; e < e1; ++e) { const int c = s_cnt[e]; lc += (c + GP - 1) / GP * GP; lo += (c > 0); }
-  int tot_v, tot_c;
+  int lc = 0;
+  for (int e = e0; e < e1; ++e) lc += s_cnt[e];
+  int tot_v;
   int run_v = block_excl_scan(lc, s_wave, &tot_v);
-  int run_c = block_excl_scan(lo, s_wave, &tot_c);
   for (int e = e0; e < e1; ++e) {
     const int c = s_cnt[e];
-    const int cp = (c + GP - 1) / GP * GP;        // records incl. padding
-    if (c > 0) {
-      const int cy = e / GW, cx = e - cy * GW;
-      CLn[run_c++] = make_float4((float)(cx - SM), (float)(cy - SM), __int_as_float(run_v), __int_as_float(cp));
-      for (int i = run_v + c; i < run_v + cp; ++i)   // sentinels: far away, never win (index = INT_MAX)
-        SRn[i] = make_float4(1e9f, 1e9f, __int_as_float(0x7fffffff), 0.0f);
-    }
-    s_cnt[e] = run_v;                            // placement cursor
-    run_v += cp;
+    s_cnt[e] = run_v;
+    run_v += c;
   }
-  // sentinel cells: pad to a multiple of GP plus one spare group (the stream prefetches one past)
-  if (tid < 2 * GP) {
-    const int padded = (tot_c + GP - 1) / GP * GP + GP;
-    const int i = tot_c + tid;
-    if (i < padded && i < ccap) CLn[i] = make_float4(1e9f, 1e9f, __int_as_float(0), __int_as_float(0));
-  }
-  __syncthreads();
-  if (tid == 0) hdr[n] = make_int4(tot_c, tot_v, s_nout, 0);
+  const int nout = s_nout;
   __syncthreads();
   if (tid == 0) s_nout = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < IPT_MAX; ++j) {
-    const int v = tid + j * BIN_T;
-    if (pc[j] >= 0) {
-      const int dst = atomicAdd(&s_cnt[pc[j]], 1);
-      SRn[dst] = make_float4(pu[j], pv[j], __int_as_float(v), 0.0f);
-    } else if (pc[j] == -1) {
-      const int dst = tot_v + atomicAdd(&s_nout, 1);
-      SRn[dst] = make_float4(pu[j], pv[j], __int_as_float(v), 0.0f);
+    const int v = tid + j * SF_T;
+    int dst = -1;
+    if (pc[j] >= 0) dst = atomicAdd(&s_cnt[pc[j]], 1);
+    else if (pc[j] == -1) dst = tot_v + atomicAdd(&s_nout, 1);
+    if (dst >= 0) { sU[dst] = pu[j]; sV[dst] = pv[j]; sI[dst] = v; }
+  }
+  __syncthreads();
+  // ---- pixels: a wave takes 4 x 4 tiles, 4 lanes per pixel
+  const int lane = tid & 63, wv = tid >> 6;
+  const int sub = lane & 3, pq = lane >> 2;                // lane of the pixel's quad, pixel of the tile
+  const int tpr = (W + 3) / 4, ntile = tpr * tpr;
+#define SMPLR_SILH_VERTEX(i_)                                                                   \
+  {                                                                                             \
+    const float du_ = sU[i_] - fc, dv_ = sV[i_] - fr;                                           \
+    const unsigned long long k_ =                                                               \
+        ((unsigned long long)__float_as_uint(fmaf(du_, du_, dv_ * dv_)) << 32) | (unsigned int)sI[i_]; \
+    best = k_ < best ? k_ : best;                                                               \
+  }
+  for (int tile = wv * gridDim.y + blockIdx.y; tile < ntile; tile += (SF_T / 64) * gridDim.y) {
+    const int ty = tile / tpr, tx = tile - ty * tpr;
+    const int r_ = ty * 4 + (pq >> 2), c_ = tx * 4 + (pq & 3);
+    const bool live = r_ < W && c_ < W;
+    const int r = min(r_, W - 1), c = min(c_, W - 1);      // clamped lanes repeat a border pixel
+    const float fc = (float)c, fr = (float)r;
+    const int cx = c + SM, cy = r + SM;
+    unsigned long long best = ~0ull;                       // (d^2 bits << 32) | vertex index; d^2 >= 0: bit order = value order
+    // (1) nearest occupied cell centre: rows sub, sub + 4, ...
+    unsigned long long near = ~0ull;                       // (d^2 bits << 32) | cell
+    // rows cy, cy +- 1, cy +- 2, ... (this lane: offsets sub, sub + 4, ...); a lane stops once the
+    // row offset alone exceeds its own best (such rows cannot beat it, hence not the quad's minimum)
+    for (int k = sub; k < GW; k += 4) {
+      const float fk = (float)k;
+      if ((unsigned long long)__float_as_uint(fk * fk) << 32 > near) break;
+#pragma unroll
+      for (int sgn = 0; sgn < 2; ++sgn) {
+        const int y = sgn ? cy - k : cy + k;
+        if (y < 0 || y >= GW || (sgn && k == 0)) continue;
+        const unsigned long long m0 = rowmask[2 * y], m1 = ONEWORD ? 0ull : rowmask[2 * y + 1];
+        if ((m0 | m1) == 0ull) continue;
+        const int off = ONEWORD ? nearest_bit1(m0, cx) : nearest_bit(m0, m1, cx);
+        const float dx = (float)off;
+        const unsigned long long kk =
+            ((unsigned long long)__float_as_uint(fmaf(dx, dx, fk * fk)) << 32) | (unsigned int)(y * GW + cx + off);
+        near = kk < near ? kk : near;
+      }
+    }
+    near = quad_min(near);
+    if (near != ~0ull) {
+      // (2) the nearest cell's vertices, every fourth one per lane
+      {
+        const int e = (int)(near & 0xffffffffull);
+        const int i0 = e ? s_cnt[e - 1] : 0, i1 = s_cnt[e];
+        for (int i = i0 + sub; i < i1; i += 4) SMPLR_SILH_VERTEX(i)
+        best = quad_min(best);
+      }
+      // (3) every occupied cell whose centre is within R = d1 + 0.7072 (+ rounding slack)
+      const float d1 = sqrtf(__uint_as_float((unsigned int)(best >> 32)));
+      const float R = d1 + 0.7072f;
+      const float R2 = R * R * 1.0001f;
+      const int rad = (int)R + 1;
+      const int ylo = max(0, cy - rad), yhi = min(GW - 1, cy + rad);
+      for (int y = ylo + sub; y <= yhi; y += 4) {
+        const float dy = (float)(y - cy);
+        const float rem = R2 - dy * dy;
+        if (rem < 0.0f) continue;
+        const int w = (int)sqrtf(rem) + 1;                 // generous: every cell is tested exactly below
+        const int xlo = max(0, cx - w), xhi = min(GW - 1, cx + w);
+        unsigned long long m0 = rowmask[2 * y], m1 = ONEWORD ? 0ull : rowmask[2 * y + 1];
+        if (xlo < 64) m0 &= ~((1ull << xlo) - 1ull); else { m0 = 0ull; m1 &= ~((1ull << (xlo - 64)) - 1ull); }
+        if (xhi < 63) { m0 &= (2ull << xhi) - 1ull; m1 = 0ull; }
+        else if (xhi == 63) m1 = 0ull;
+        else if (xhi < 127) m1 &= (2ull << (xhi - 64)) - 1ull;
+        for (int half = 0; half < (ONEWORD ? 1 : 2); ++half) {
+          unsigned long long m = half ? m1 : m0;
+          while (m) {
+            const int x = (__ffsll((long long)m) - 1) + 64 * half;
+            m &= m - 1ull;
+            const float dx = (float)(x - cx);
+            if (fmaf(dx, dx, dy * dy) <= R2) {
+              const int e = y * GW + x;
+              const int i0 = e ? s_cnt[e - 1] : 0, i1 = s_cnt[e];
+              for (int i = i0; i < i1; ++i) SMPLR_SILH_VERTEX(i)
+            }
+          }
+        }
+      }
+    }
+    for (int i = tot_v + sub; i < tot_v + nout; i += 4) SMPLR_SILH_VERTEX(i)     // outliers: always
+    best = quad_min(best);
+    if (live && sub == 0) {
+      float score = 0.0f;
+      int pos = -1;
+      if (best != ~0ull) {
+        score = expf(-sqrtf(__uint_as_float((unsigned int)(best >> 32))) / 1.2f);
+        pos = (int)(best & 0xffffffffull);
+      }
+      const size_t o = ((size_t)n * W + (W - 1 - r)) * W + c;   // rows flipped (:42)
+      out[o * 2 + 0] = 1.0f - score;
+      out[o * 2 + 1] = score;
+      arg_out[o] = pos;
     }
   }
-}
-
-#define SMPLR_SILH_EVAL(rec, ok)                                                      \
-  {                                                                                   \
-    const float du_ = (rec).x - fc, dv_ = (rec).y - fr;                               \
-    const float key_ = fmaf(du_, du_, dv_ * dv_);                                     \
-    const int id_ = __float_as_int((rec).z);                                          \
-    if ((ok) && (key_ < best || (key_ == best && id_ < bidx))) { best = key_; bidx = id_; } \
-  }
-
-__global__ __launch_bounds__(RT) void silh_fwd_pruned_kernel(const float4 *__restrict__ CL,
-                                                             const float4 *__restrict__ SR,
-                                                             const int4 *__restrict__ hdr, int ccap, int vcap,
-                                                             int W, float *__restrict__ out,
-                                                             int *__restrict__ arg_out) {
-  const int n = blockIdx.y;
-  const int q = blockIdx.x * RT + threadIdx.x;
-  const int npix = W * W;
-  const bool live = q < npix;
-  const int qc = live ? q : npix - 1;
-  const int r = qc / W, c = qc - r * W;
-  const float fc = (float)c, fr = (float)r;
-  const float4 *CLn = CL + (size_t)n * ccap;
-  const float4 *SRn = SR + (size_t)n * vcap;
-  const int4 h = hdr[n];
-  const int ncells = __builtin_amdgcn_readfirstlane(h.x), out_start = __builtin_amdgcn_readfirstlane(h.y),
-            nout = __builtin_amdgcn_readfirstlane(h.z);
-  const int kend = (ncells + GP - 1) / GP * GP;
-  // pass 1: squared distance to the nearest occupied cell centre (cells stream as scalar operands)
-  float dmin2 = INFINITY;
-  if (kend > 0) {
-    f32x16s ga, gb;
-    const float4 *gp = CLn;
-    sload_group(ga, gp);
-    swait_group(ga);
-    int k = 0;
-#define SMPLR_CELL_D2(g, j) fmaf((g)[4 * (j)] - fc, (g)[4 * (j)] - fc, ((g)[4 * (j) + 1] - fr) * ((g)[4 * (j) + 1] - fr))
-    while (true) {
-      sload_group(gb, gp + GP);
-      dmin2 = fminf(fminf(dmin2, SMPLR_CELL_D2(ga, 0)), fminf(SMPLR_CELL_D2(ga, 1), fminf(SMPLR_CELL_D2(ga, 2), SMPLR_CELL_D2(ga, 3))));
-      swait_group(gb);
-      k += GP;
-      if (k >= kend) break;
-      sload_group(ga, gp + 2 * GP);
-      dmin2 = fminf(fminf(dmin2, SMPLR_CELL_D2(gb, 0)), fminf(SMPLR_CELL_D2(gb, 1), fminf(SMPLR_CELL_D2(gb, 2), SMPLR_CELL_D2(gb, 3))));
-      swait_group(ga);
-      k += GP;
-      gp += 2 * GP;
-      if (k >= kend) break;
-    }
-  }
-  const float T = sqrtf(dmin2) + 1.4143f;
-  const float T2 = (dmin2 < 1e17f) ? T * T * 1.0001f : -1.0f;
-  // pass 2: exact evaluation of the vertices of every cell whose centre is within T
-  float best = INFINITY;
-  int bidx = 0x7fffffff;
-#define SMPLR_SILH_GROUP(g)                                                                         \
-  SMPLR_SILH_EVAL(make_float4((g)[0], (g)[1], (g)[2], 0.f), cand)                                   \
-  SMPLR_SILH_EVAL(make_float4((g)[4], (g)[5], (g)[6], 0.f), cand)                                   \
-  SMPLR_SILH_EVAL(make_float4((g)[8], (g)[9], (g)[10], 0.f), cand)                                  \
-  SMPLR_SILH_EVAL(make_float4((g)[12], (g)[13], (g)[14], 0.f), cand)
-  // one cell: candidate test; its records (padded to whole groups) stream as scalar operands
-#define SMPLR_SILH_CELL(cg, j)                                                                      \
-  {                                                                                                 \
-    const float dx_ = (cg)[4 * (j)] - fc, dy_ = (cg)[4 * (j) + 1] - fr;                             \
-    const bool cand = fmaf(dx_, dx_, dy_ * dy_) <= T2;                                              \
-    if (__any(cand)) {                                                                              \
-      const int st_ = __builtin_amdgcn_readfirstlane(__float_as_int((cg)[4 * (j) + 2]));            \
-      const int cp_ = __builtin_amdgcn_readfirstlane(__float_as_int((cg)[4 * (j) + 3]));            \
-      f32x16s va, vb;                                                                               \
-      const float4 *vp_ = SRn + st_;                                                                \
-      sload_group(va, vp_);                                                                         \
-      swait_group(va);                                                                              \
-      int jj_ = 0;                                                                                  \
-      while (true) {                                                                                \
-        sload_group(vb, vp_ + GP);                                                                  \
-        SMPLR_SILH_GROUP(va)                                                                        \
-        swait_group(vb);                                                                            \
-        jj_ += GP;                                                                                  \
-        if (jj_ >= cp_) break;                                                                      \
-        sload_group(va, vp_ + 2 * GP);                                                              \
-        SMPLR_SILH_GROUP(vb)                                                                        \
-        swait_group(va);                                                                            \
-        jj_ += GP;                                                                                  \
-        vp_ += 2 * GP;                                                                              \
-        if (jj_ >= cp_) break;                                                                      \
-      }                                                                                             \
-    }                                                                                               \
-  }
-  if (kend > 0) {
-    f32x16s ca, cb;
-    const float4 *gp = CLn;
-    sload_group(ca, gp);
-    swait_group(ca);
-    int k = 0;
-    while (true) {
-      sload_group(cb, gp + GP);
-      swait_group(cb);          // the cells' inner streams use lgkmcnt too: keep this group's wait simple
-      SMPLR_SILH_CELL(ca, 0) SMPLR_SILH_CELL(ca, 1) SMPLR_SILH_CELL(ca, 2) SMPLR_SILH_CELL(ca, 3)
-      k += GP;
-      if (k >= kend) break;
-      sload_group(ca, gp + 2 * GP);
-      swait_group(ca);
-      SMPLR_SILH_CELL(cb, 0) SMPLR_SILH_CELL(cb, 1) SMPLR_SILH_CELL(cb, 2) SMPLR_SILH_CELL(cb, 3)
-      k += GP;
-      gp += 2 * GP;
-      if (k >= kend) break;
-    }
-  }
-  for (int j = out_start; j < out_start + nout; ++j) {                // outliers: always
-    const float4 rec = SRn[j];
-    SMPLR_SILH_EVAL(rec, true)
-  }
-  float score = 0.0f;
-  int pos = -1;
-  if (best < INFINITY) {
-    score = expf(-sqrtf(best) / 1.2f);
-    pos = bidx;
-  }
-  if (live) {
-    const size_t o = ((size_t)n * W + (W - 1 - r)) * W + c;   // rows flipped (:42)
-    out[o * 2 + 0] = 1.0f - score;
-    out[o * 2 + 1] = score;
-    arg_out[o] = pos;
-  }
+#undef SMPLR_SILH_VERTEX
 }
 
 __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict__ dsilh,
@@ -1169,9 +1172,7 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
 size_t smplr_silh_workspace(int B, int VP, int W) {
   if (B <= 0 || VP <= 0 || W <= 0) return 0;
   const int KP = (VP + smplr::CH - 1) / smplr::CH * smplr::CH;
-  const size_t brute = (size_t)B * KP * 4 * sizeof(float);
-  const size_t pruned = (W <= smplr::SILH_WMAX && VP <= smplr::BIN_T * smplr::IPT_MAX) ? smplr::silh_ws_layout(B, VP, W).total : 0;
-  return brute > pruned ? brute : pruned;
+  return (size_t)B * KP * 4 * sizeof(float);     // only the brute-force fallback uses it
 }
 
 int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg, void *workspace,
@@ -1181,20 +1182,18 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
   if (B == 0) return 0;
   SMPLR_REQUIRE(proj && silh && arg && workspace, "smplr_silh_fwd: null pointer");
   hipStream_t st = as_stream(stream);
-  if (W <= SILH_WMAX && VP <= BIN_T * IPT_MAX) {
-    const SilhWs ws = silh_ws_layout(B, VP, W);
-    char *base = reinterpret_cast<char *>(workspace);
-    float4 *CL = reinterpret_cast<float4 *>(base + ws.cl_off);
-    float4 *SR = reinterpret_cast<float4 *>(base + ws.sr_off);
-    int4 *hdr = reinterpret_cast<int4 *>(base + ws.hdr_off);
-    const int GW = W + 2 * SM;
-    const size_t lds = (size_t)GW * GW * sizeof(int);
-    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bin_kernel), lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(silh_bin_kernel, dim3(B), dim3(BIN_T), lds, st, proj, VP, W, ws.ccap, ws.vcap, CL, SR, hdr);
-    SMPLR_LAUNCH_CHECK("smplr_silh_fwd(bin)");
-    hipLaunchKernelGGL(silh_fwd_pruned_kernel, dim3((W * W + RT - 1) / RT, B), dim3(RT), 0, st, CL, SR, hdr, ws.ccap,
-                       ws.vcap, W, silh, arg);
+  if (W <= SILH_WMAX && VP <= SF_T * IPT_MAX && silh_fused_lds(VP, W) <= 150 * 1024) {
+    const size_t lds = silh_fused_lds(VP, W);
+    const int nsplit = B >= 256 ? 1 : (B >= 128 ? 2 : 4);      // one workgroup per CU (256 CUs)
+    if (W + 2 * SM <= 64) {
+      int rc = set_lds_attr(reinterpret_cast<const void *>(silh_fused_kernel<true>), lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(silh_fused_kernel<true>, dim3(B, nsplit), dim3(SF_T), lds, st, proj, VP, W, silh, arg);
+    } else {
+      int rc = set_lds_attr(reinterpret_cast<const void *>(silh_fused_kernel<false>), lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL(silh_fused_kernel<false>, dim3(B, nsplit), dim3(SF_T), lds, st, proj, VP, W, silh, arg);
+    }
     SMPLR_LAUNCH_CHECK("smplr_silh_fwd");
     return 0;
   }
