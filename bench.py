@@ -326,6 +326,14 @@ def main():
                     {"graph_meshes_per_s": round(256 / (t_g * 1e-3), 1), "graph_ms_per_step": round(t_g, 4)})
             except Exception as e:
                 line["aux"]["batch_smpl_fwd_bwd_B256"]["graph_error"] = str(e)
+            # silhouette rasteriser (part of configs[4]'s second loss), same meshes
+            c0s = ops._pose_fwd(x, 4, consts)
+            pjs = ops._skin_fwd(ops._blend_fwd(c0s[0], consts, x.shape[0]), c0s[3], consts, cam=x)[1]
+            sil, sarg = ops._silh_fwd(pjs, W)
+            dsil = torch.randn_like(sil)
+            t_sf = event_time_ms(lambda: ops._silh_fwd(pjs, W), 20, torch.cuda.current_stream())
+            t_sb = event_time_ms(lambda: ops._silh_bwd(dsil, sil, sarg, pjs, W), 20, torch.cuda.current_stream())
+            line["aux"]["silhouette"] = {"fwd_us": round(t_sf * 1e3, 2), "bwd_us": round(t_sb * 1e3, 2), "meshes": B}
             # loss head: softmax + focal loss on the (B,W,W,32) scores, HBM-bound.
             # algorithmic bytes: fwd = scores 128 + label 4 + loss 4 B/pixel; bwd = 128 + 4 + 4 + 128 B/pixel
             seg_s = torch.rand(B, W, W, 32, device=dev)
