@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMPLR_ABI_VERSION 1
+#define SMPLR_ABI_VERSION 2
 #define SMPLR_NJ 24            /* joints                                   */
 #define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
 #define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
@@ -50,12 +50,16 @@ const char *smplr_last_error(void);
  *   coef  (220, ld)      k-MAJOR, ld = smplr_coef_ld(B) = B rounded up to 32: column n =
  *                        [beta(10) | pose_feature(207) | 0,0,0] of mesh n - the blend GEMM's A operand,
  *                        laid out so that the matrix cores read it without a transpose
+ *   coef3 (smplr_coef3_bytes(B) bytes) the same columns split into three bf16 terms per entry and laid
+ *                        out as MFMA A-fragments - the operand of smplr_blend3_fwd.  coef or coef3 may be
+ *                        NULL (at least one is required).
  *   Rs    (B,24,9)  J (B,24,3)  A (B,24,12) = rows 0..2 of the reference's (4,4) A
  *   J_transformed (B,24,3)  (batch_smpl.py:131, :216)                                      */
 int smplr_coef_ld(int B);
+size_t smplr_coef3_bytes(int B);
 int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B,
                    const float *J_template, const float *J_dirs, const int32_t *parents,
-                   float *coef, float *Rs, float *J, float *A, float *J_transformed,
+                   float *coef, void *coef3, float *Rs, float *J, float *A, float *J_transformed,
                    void *stream);
 
 /* Backward of the above.  dcoef (B,220), dA (B,24,12), dJ_transformed (B,24,3) or NULL,
@@ -80,6 +84,26 @@ int smplr_blend_fwd(const float *coef, const float *blend, const float *v_templa
 size_t smplr_blend_bwd_workspace(int B, int N3);
 int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3,
                     float *dcoef, void *workspace, void *stream);
+
+/* The same two GEMMs on the bf16 matrix cores with fp32-grade operands ("bf16x3"; the default of
+ * the Python host side).  Every fp32 operand is the exact sum of three bf16 numbers (3 x 8 = 24
+ * significant bits); a product is accumulated in fp32 from its six partial products of relative
+ * size >= 2^-16 (what is dropped is < 2^-24 of the product, below an fp32 product's own rounding).
+ * The constant is split and laid out in MFMA fragment order once:
+ *   smplr_blend3_pack(blend (220,N3) fp32) -> pk_fwd (smplr_blend3_fwd_bytes(N3) bytes) and/or
+ *   pk_bwd (smplr_blend3_bwd_bytes(N3) bytes); either may be NULL.
+ * smplr_blend3_fwd / smplr_blend3_bwd then have the semantics of smplr_blend_fwd / smplr_blend_bwd
+ * (dv_posed, v_posed, dcoef are fp32 in memory; the forward's per-step operand is smplr_pose_fwd's
+ * coef3, split once per mesh instead of once per column tile; workspace: smplr_blend3_bwd_workspace). */
+int smplr_coef3_pack(const float *coef, int B, void *coef3, void *stream);   /* coef (k-major) -> coef3 */
+size_t smplr_blend3_fwd_bytes(int N3);
+size_t smplr_blend3_bwd_bytes(int N3);
+int smplr_blend3_pack(const float *blend, int N3, void *pk_fwd, void *pk_bwd, void *stream);
+int smplr_blend3_fwd(const void *coef3, const void *pk_fwd, const float *v_template,
+                     int B, int N3, float *v_posed, void *stream);
+size_t smplr_blend3_bwd_workspace(int B, int N3);
+int smplr_blend3_bwd(const float *dv_posed, const void *pk_bwd, int B, int N3,
+                     float *dcoef, void *workspace, void *stream);
 
 /* Linear-blend skinning (batch_smpl.py:135-145) with the orthographic projection
  * (projection.py:54-81) as an optional epilogue.
@@ -108,11 +132,13 @@ int smplr_skin_bwd(const float *dverts, const float *dproj,
 /* Fused backward of the whole SMPLLayer (+ projection epilogue): smplr_skin_bwd -> smplr_blend_bwd ->
  * smplr_pose_bwd in three launches, the partial sums of the first two folded into the third
  * (fixed summation order).  Same semantics as chaining the three entry points above.
+ * The blend GEMM uses blend3_bwd (smplr_blend3_pack's pk_bwd) when it is not NULL, else blend_t.
  * workspace: smplr_smpl_bwd_workspace(B,V) bytes.                                              */
 size_t smplr_smpl_bwd_workspace(int B, int V);
 int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed,
                    const float *x, int x_stride, int num_cam, int B, int V, int vertex_sampling,
-                   const float *blend_t, const float *lbs_weights, const float *lbs_top4,
+                   const float *blend_t, const void *blend3_bwd,
+                   const float *lbs_weights, const float *lbs_top4,
                    const float *J_dirs, const int32_t *parents, const float *Rs, const float *J, const float *A,
                    const float *v_posed, float *dx, void *workspace, void *stream);
 

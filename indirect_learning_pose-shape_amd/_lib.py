@@ -26,16 +26,24 @@ SIGNATURES = {
     "smplr_abi_version": (c_int, []),
     "smplr_last_error": (c_char_p, []),
     "smplr_coef_ld": (c_int, [I]),
-    "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P]),
+    "smplr_coef3_bytes": (c_size_t, [I]),
+    "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "smplr_pose_bwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P, P]),
     "smplr_blend_fwd": (c_int, [P, P, P, I, I, P, P]),
     "smplr_blend_bwd_workspace": (c_size_t, [I, I]),
     "smplr_blend_bwd": (c_int, [P, P, I, I, P, P, P]),
+    "smplr_coef3_pack": (c_int, [P, I, P, P]),
+    "smplr_blend3_fwd_bytes": (c_size_t, [I]),
+    "smplr_blend3_bwd_bytes": (c_size_t, [I]),
+    "smplr_blend3_pack": (c_int, [P, I, P, P, P]),
+    "smplr_blend3_fwd": (c_int, [P, P, P, I, I, P, P]),
+    "smplr_blend3_bwd_workspace": (c_size_t, [I, I]),
+    "smplr_blend3_bwd": (c_int, [P, P, I, I, P, P, P]),
     "smplr_skin_fwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P]),
     "smplr_skin_bwd_workspace": (c_size_t, [I, I]),
     "smplr_skin_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "smplr_smpl_bwd_workspace": (c_size_t, [I, I]),
-    "smplr_smpl_bwd": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "smplr_smpl_bwd": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "smplr_project_fwd": (c_int, [P, P, I, I, I, I, P, P]),
     "smplr_project_bwd": (c_int, [P, P, P, I, I, I, I, P, P, P]),
     "smplr_visibility": (c_int, [P, I, I, I, I, P, P]),
@@ -72,7 +80,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.smplr_abi_version() != 1:
+    if lib.smplr_abi_version() != 2:
         raise RuntimeError("libsmplraster_hip.so ABI version mismatch")
     _lib = lib
     return lib

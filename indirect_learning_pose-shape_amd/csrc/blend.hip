@@ -298,6 +298,13 @@ int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B
   return 0;
 }
 
+int launch_blend_bwd_reduce(const float *part, int B, int nslices, int nmt, float *dcoef, hipStream_t st) {
+  hipLaunchKernelGGL(blend_bwd_reduce_kernel, dim3((B * KP + 255) / 256), dim3(256), 0, st, part, B, nslices, nmt,
+                     dcoef);
+  SMPLR_LAUNCH_CHECK("blend_bwd_reduce_kernel");
+  return 0;
+}
+
 }  // namespace smplr
 
 extern "C" {
@@ -334,10 +341,7 @@ int smplr_blend_bwd(const float *dv_posed, const float *blend_t, int B, int N3, 
   int rc = launch_blend_bwd_partials(dv_posed, blend_t, B, N3, reinterpret_cast<float *>(workspace),
                                      as_stream(stream));
   if (rc) return rc;
-  hipLaunchKernelGGL(blend_bwd_reduce_kernel, dim3((B * KP + 255) / 256), dim3(256), 0,
-                     as_stream(stream), reinterpret_cast<const float *>(workspace), B, ns, nmt, dcoef);
-  SMPLR_LAUNCH_CHECK("smplr_blend_bwd(reduce)");
-  return 0;
+  return launch_blend_bwd_reduce(reinterpret_cast<const float *>(workspace), B, ns, nmt, dcoef, as_stream(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,425 @@
+// K2' blend-shape GEMMs on the bf16 matrix cores with fp32-grade operands ("bf16x3").
+//
+//   forward : v_posed (B,N3) = coef (B,220) x blend (220,N3) + v_template      (N3 = 20670)
+//   backward: dcoef  (B,220) = dv_posed (B,N3) x blend^T                         (split-K)
+//
+// Reference: keras_smpl/batch_smpl.py:106-108 and :126-128 (the two K.dot), as in blend.hip.
+//
+// gfx950 has no reduced-precision fast path for fp32 operands: v_mfma_f32_32x32x2_f32 runs at the
+// vector rate, 1/16 of the bf16 matrix rate, and the two GEMMs above are a fifth of the decoder
+// step at B = 128.  Here every fp32 operand is written as the exact sum of three bf16 numbers,
+//      a = a_h + a_m + a_l,   a_h = bf16(a), a_m = bf16(a - a_h), a_l = bf16(a - a_h - a_m)
+// (round to nearest; 3 x 8 significant bits cover the 24 of an fp32, the residuals are exact in
+// fp32), and a product a*b as the six partial products of relative size >= 2^-16,
+//      a_h b_h  +  (a_h b_m + a_m b_h)  +  (a_h b_l + a_m b_m + a_l b_h),
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three
+// dropped products are below 2^-24 of |a b|, i.e. below the rounding of an fp32 product itself.
+// The leading product and the five corrections go to separate accumulators that are added once
+// at the end, so small terms are not absorbed one by one into a large sum.  Six bf16 MFMAs of
+// K = 16 take 192 cycles against 512 for the eight fp32 MFMAs of K = 2 they replace; both GEMMs
+// then run at the rate the packed constant (27 MB) streams in.  Measured error against the
+// float64 oracle: see tests/test_gpu_parity.py::test_blend3_matches_fp32_path.
+//
+// The constant operand is split and laid out in MFMA fragment order ONCE (smplr_blend3_pack), so
+// a wave reads each 64-lane fragment with one coalesced 1-KB global_load_dwordx4; the per-step
+// operand (coef, dv_posed) is fp32 in memory and split in registers (v_cvt_pk_bf16_f32).
+//   forward operand  [96-col tile][k-tile 14][t 3][split 3][lane 64][8 bf16]:
+//       element j of lane (i, h) = split_s(blend[16 kt + 8h + j][96 ct + 3i + t])
+//   backward operand [k-tile ceil(N3/16)][out tile 7][split 3][lane 64][8 bf16]:
+//       element j of lane (i, h) = split_s(blend[32u + i][16 kt + 8h + j])
+// (zeros beyond row 219 / column N3 - 1).
+#include "common.h"
+
+namespace smplr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+
+constexpr int KP = SMPLR_KPAD;       // 220
+constexpr int NKT = 14;              // forward k-tiles of 16 (224 >= 220)
+constexpr int F3_BN = 96;            // forward column tile (3 MFMA tiles; lane i owns columns 3i..3i+2)
+constexpr int B3_NO = 224;           // backward outputs (7 tiles) = partial row stride
+
+#define SMPLR_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+// the six partial products of one (A fragment, B fragment triple); smallest first into `lo`
+#define SMPLR_MFMA_X3(A, bh, bm, bl, hi, lo) \
+  lo = SMPLR_MFMA16(A.l, bh, lo);            \
+  lo = SMPLR_MFMA16(A.h, bl, lo);            \
+  lo = SMPLR_MFMA16(A.m, bm, lo);            \
+  lo = SMPLR_MFMA16(A.m, bh, lo);            \
+  lo = SMPLR_MFMA16(A.h, bm, lo);            \
+  hi = SMPLR_MFMA16(A.h, bh, hi);
+
+// ------------------------------------------------------------------------------------------------
+// one-off packing of the constant (not on the hot path)
+__global__ __launch_bounds__(256) void blend3_pack_fwd_kernel(const float *__restrict__ blend, int N3, int ntile,
+                                                              uint4 *__restrict__ pk) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;           // (ct, kt, t, lane)
+  if (e >= (size_t)ntile * NKT * 3 * 64) return;
+  const int lane = e & 63, t = (e >> 6) % 3, kt = (e / 192) % NKT, ct = e / (192 * NKT);
+  const int i = lane & 31, h = lane >> 5;
+  const int col = ct * F3_BN + 3 * i + t;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kt * 16 + 8 * h + j;
+    x[j] = (k < KP && col < N3) ? blend[(size_t)k * N3 + col] : 0.0f;
+  }
+  const Frag3 f = split8(x);
+  uint4 *o = pk + ((size_t)(ct * NKT + kt) * 9 + t * 3) * 64 + lane;
+  o[0] = __builtin_bit_cast(uint4, f.h);
+  o[64] = __builtin_bit_cast(uint4, f.m);
+  o[128] = __builtin_bit_cast(uint4, f.l);
+}
+
+__global__ __launch_bounds__(256) void blend3_pack_bwd_kernel(const float *__restrict__ blend, int N3, int nkt,
+                                                              uint4 *__restrict__ pk) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;           // (kt, u, lane)
+  if (e >= (size_t)nkt * 7 * 64) return;
+  const int lane = e & 63, u = (e >> 6) % 7, kt = e / (64 * 7);
+  const int i = lane & 31, h = lane >> 5;
+  const int o_ = 32 * u + i;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = kt * 16 + 8 * h + j;
+    x[j] = (o_ < KP && c < N3) ? blend[(size_t)o_ * N3 + c] : 0.0f;
+  }
+  const Frag3 f = split8(x);
+  uint4 *o = pk + ((size_t)(kt * 7 + u) * 3) * 64 + lane;
+  o[0] = __builtin_bit_cast(uint4, f.h);
+  o[64] = __builtin_bit_cast(uint4, f.m);
+  o[128] = __builtin_bit_cast(uint4, f.l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// coef (220, ld) k-major fp32 -> coef3, the A-fragment layout smplr_pose_fwd writes directly
+// ([mesh tile][k-tile 14][split 3][lane 64] x 16 B; lane (i, h) = mesh 32 mt + i, k = 16 kt + 8h + j).
+__global__ __launch_bounds__(256) void coef3_pack_kernel(const float *__restrict__ coef, int B, int ldc,
+                                                         u32x4 *__restrict__ coef3) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                      // (mt, kt, lane)
+  const int nmt = (B + 31) / 32;
+  if (e >= nmt * NKT * 64) return;
+  const int lane = e & 63, kt = (e >> 6) % NKT, mt = e / (64 * NKT);
+  const int i = lane & 31, h = lane >> 5, m = mt * 32 + i;
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kt * 16 + 8 * h + j;
+    x[j] = (k < KP && m < B) ? coef[(size_t)k * ldc + m] : 0.0f;
+  }
+  const Frag3 f = split8(x);
+  u32x4 *o = coef3 + ((size_t)(mt * NKT + kt) * 3) * 64 + lane;
+  o[0] = __builtin_bit_cast(u32x4, f.h);
+  o[64] = __builtin_bit_cast(u32x4, f.m);
+  o[128] = __builtin_bit_cast(u32x4, f.l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward.  grid (column tiles of 96, groups of 128 meshes); workgroup = 4 waves = the 4 mesh
+// tiles of one column tile (identical requests for the constant: L1 serves three of the four), each
+// wave a 32 x 96 tile = 3 (leading, correction) accumulator pairs.  Per k-tile a lane requests
+// 3 x 16 B of coef3 and 9 x 16 B of the packed constant, every request a contiguous 1 KB per wave;
+// F3_DEPTH k-tiles are in flight ahead of the one being multiplied.  Both operands arrive as
+// fragments: no conversion and no address arithmetic in the loop.
+// Measured (B = 128, rocprofv3): 14 us against 18.7 us for the fp32 matrix-core kernel; with the
+// constant served from L2 it takes 12 us and without its stores 10 us, so what is left is launch,
+// the first round trip, 252 MFMAs and the drain of 10.6 MB of output.  Rejected on the way (same
+// numerics): the constant shared through LDS with each wave fetching a quarter (16.4 us), eight
+// waves splitting K in pairs with an LDS hand-over (15.4 us).
+constexpr int F3_DEPTH = 3;
+
+__global__ __launch_bounds__(256) void blend3_fwd_kernel(const u32x4 *__restrict__ coef3,
+                                                         const u32x4 *__restrict__ pk,
+                                                         const float *__restrict__ vt, int B, int N3,
+                                                         float *__restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = (blockIdx.y * 4 + wave) * 32;
+  if (m0 >= B) return;                                   // this wave's mesh tile is empty
+  const int i = lane & 31, h = lane >> 5;
+  const int c = blockIdx.x * F3_BN + 3 * i;
+  const u32x4 *ap = coef3 + (size_t)(m0 >> 5) * (NKT * 3 * 64) + lane;
+  const u32x4 *bp = pk + (size_t)blockIdx.x * (NKT * 9 * 64) + lane;
+
+  f32x16 hi[3], lo[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hi[t][r] = 0.0f; lo[t][r] = 0.0f; }
+
+  u32x4 a[F3_DEPTH + 1][3], b[F3_DEPTH + 1][9];
+#define SMPLR_LOAD_KT(slot, kt)                                                         \
+  {                                                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) a[slot][s_] = ap[((kt) * 3 + s_) * 64]; \
+    _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) b[slot][j_] = bp[((kt) * 9 + j_) * 64]; \
+  }
+#pragma unroll
+  for (int kt = 0; kt < F3_DEPTH; ++kt) { SMPLR_LOAD_KT(kt % (F3_DEPTH + 1), kt) }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (kt + F3_DEPTH < NKT) { SMPLR_LOAD_KT((kt + F3_DEPTH) % (F3_DEPTH + 1), kt + F3_DEPTH) }
+    __builtin_amdgcn_sched_barrier(0);
+    const int s = kt % (F3_DEPTH + 1);
+    Frag3 A;
+    A.h = __builtin_bit_cast(bf16x8, a[s][0]);
+    A.m = __builtin_bit_cast(bf16x8, a[s][1]);
+    A.l = __builtin_bit_cast(bf16x8, a[s][2]);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, b[s][t * 3 + 0]);
+      const bf16x8 bm = __builtin_bit_cast(bf16x8, b[s][t * 3 + 1]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, b[s][t * 3 + 2]);
+      SMPLR_MFMA_X3(A, bh, bm, bl, hi[t], lo[t])
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SMPLR_LOAD_KT
+
+  float base[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) base[t] = vt[min(c + t, N3 - 1)];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int m = m0 + row;
+    if (m < B) {
+      float *o = out + (size_t)m * N3 + c;
+      if (c + 3 <= N3) {
+        f32x3u v;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v[t] = (hi[t][r] + lo[t][r]) + base[t];
+        *reinterpret_cast<f32x3u *>(o) = v;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (c + t < N3) o[t] = (hi[t][r] + lo[t][r]) + base[t];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward (split-K over column slices).  Workgroup = (slice, mesh tile of 32); its 4 waves own
+// DIFFERENT output tiles (wave w: tiles w and w + 4; 7 tiles, so wave 3 has one), hence no
+// reduction inside the block and no LDS: the dv_posed fragment (8 consecutive floats of row
+// m0 + i, two dwordx4, split in registers) is requested by all four waves (L1), the packed constant
+// only by its owner.  Per-slice partials (slice, mesh tile, 32, 224) are summed in slice order by
+// pose_bwd (fused path) or blend_bwd_reduce_kernel: deterministic, no atomics.
+// Measured (B = 128): 14 us against 18.3 us for the fp32 matrix-core kernel; eight waves splitting
+// each slice in halves with an LDS hand-over: 15.7 us.
+constexpr int B3_DEPTH = 5;
+
+__global__ __launch_bounds__(256) void blend3_bwd_kernel(const float *__restrict__ dvp,
+                                                         const u32x4 *__restrict__ pk, int B, int N3,
+                                                         int ktps, int nslices, int nmt,
+                                                         float *__restrict__ part) {
+  // XCD-aware map: the nmt mesh tiles of one column slice (same constant rows) share an XCD's L2.
+  const int bid = blockIdx.x;
+  const int group = bid / (8 * nmt), within = bid % (8 * nmt);
+  const int slice = group * 8 + (within & 7), mt = within >> 3;
+  if (slice >= nslices) return;
+  const int m0 = mt * 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int u0 = wave, u1 = wave + 4 < 7 ? wave + 4 : 6;      // wave 3: second tile is a discarded copy of tile 6
+  const int nkt = (N3 + 15) / 16, nfull = N3 / 16;
+  const int kt_beg = slice * ktps;
+  const int kt_end = min(kt_beg + ktps, nkt);
+  const int kt_main = min(kt_end, nfull);                     // whole k-tiles; the matrix' ragged last tile comes after
+  const int n = kt_main > kt_beg ? kt_main - kt_beg : 0;
+
+  f32x16 hi[2], lo[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hi[t][r] = 0.0f; lo[t][r] = 0.0f; }
+
+  const int mr = min(m0 + i, B - 1);                          // rows beyond B: clamped, never stored
+  const float *arow = dvp + (size_t)mr * N3 + 8 * h;
+  const u32x4 *b0 = pk + (size_t)u0 * 192 + lane, *b1 = pk + (size_t)u1 * 192 + lane;
+
+  f32x4u ra0[B3_DEPTH + 1], ra1[B3_DEPTH + 1];
+  u32x4 rb[B3_DEPTH + 1][6];
+  // (requests are unconditional with clamped tile indices: a branch around them would park the ring in scratch)
+#define SMPLR_LOAD_KT(slot, g)                                                    \
+  {                                                                               \
+    const int kt_ = min(kt_beg + (g), nfull - 1);                                 \
+    ra0[slot] = *reinterpret_cast<const f32x4u *>(arow + (size_t)kt_ * 16);       \
+    ra1[slot] = *reinterpret_cast<const f32x4u *>(arow + (size_t)kt_ * 16 + 4);   \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                            \
+      rb[slot][s_] = b0[((size_t)kt_ * 21 + s_) * 64];                            \
+      rb[slot][3 + s_] = b1[((size_t)kt_ * 21 + s_) * 64];                        \
+    }                                                                             \
+  }
+#define SMPLR_MMA_KT(slot)                                                         \
+  {                                                                               \
+    const float x_[8] = {ra0[slot][0], ra0[slot][1], ra0[slot][2], ra0[slot][3],  \
+                         ra1[slot][0], ra1[slot][1], ra1[slot][2], ra1[slot][3]}; \
+    const Frag3 A = split8(x_);                                                   \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                            \
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 0]);         \
+      const bf16x8 bm = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 1]);         \
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 2]);         \
+      SMPLR_MFMA_X3(A, bh, bm, bl, hi[t_], lo[t_])                                \
+    }                                                                             \
+  }
+#pragma unroll
+  for (int g = 0; g < B3_DEPTH; ++g) { SMPLR_LOAD_KT(g, min(g, max(n - 1, 0))) }
+  __builtin_amdgcn_sched_barrier(0);
+  for (int g0 = 0; g0 < n; g0 += B3_DEPTH + 1) {
+#pragma unroll
+    for (int u = 0; u < B3_DEPTH + 1; ++u) {
+      const int g = g0 + u;
+      if (g < n) {                             // block-uniform
+        SMPLR_LOAD_KT((u + B3_DEPTH) % (B3_DEPTH + 1), min(g + B3_DEPTH, n - 1))
+        __builtin_amdgcn_sched_barrier(0);
+        SMPLR_MMA_KT(u)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#undef SMPLR_LOAD_KT
+#undef SMPLR_MMA_KT
+  if (kt_end > kt_main) {                      // block-uniform: the slice that owns the end of the matrix (N3 % 16 != 0)
+    const int kt = nfull;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int cc = kt * 16 + 8 * h + j;      // columns >= N3 meet zeros in the packed constant
+      x[j] = dvp[(size_t)mr * N3 + min(cc, N3 - 1)];
+    }
+    const Frag3 A = split8(x);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const u32x4 *bq = pk + ((size_t)kt * 21 + (t == 0 ? u0 : u1) * 3) * 64 + lane;
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[0]);
+      const bf16x8 bm = __builtin_bit_cast(bf16x8, bq[64]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[128]);
+      SMPLR_MFMA_X3(A, bh, bm, bl, hi[t], lo[t])
+    }
+  }
+  // accumulator register r of lane (i, h) = mesh row (r&3) + 8(r>>2) + 4h, output 32u + i
+  float *dst = part + ((size_t)slice * nmt + mt) * (32 * B3_NO);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t == 1 && wave + 4 >= 7) break;        // wave-uniform
+    const int u = t == 0 ? u0 : u1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      dst[row * B3_NO + 32 * u + i] = hi[t][r] + lo[t][r];
+    }
+  }
+}
+
+// k-tiles per slice: about one workgroup per CU, and at most 60 slices so that pose_bwd sums a
+// mesh's partials with one batch of loads.
+Blend3BwdGeom blend3_bwd_geom(int B, int N3) {
+  Blend3BwdGeom g;
+  g.nmt = (B + 31) / 32;
+  const int nkt = (N3 + 15) / 16;
+  int target = (256 + g.nmt - 1) / g.nmt;
+  if (target < 8) target = 8;
+  if (target > 60) target = 60;
+  g.ktps = (nkt + target - 1) / target;
+  g.nslices = (nkt + g.ktps - 1) / g.ktps;
+  g.part_floats = (size_t)g.nslices * g.nmt * 32 * B3_NO;
+  return g;
+}
+
+int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
+                               hipStream_t st) {
+  const Blend3BwdGeom g = blend3_bwd_geom(B, N3);
+  const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
+  hipLaunchKernelGGL(blend3_bwd_kernel, dim3(grid), dim3(256), 0, st, dv_posed,
+                     reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
+  SMPLR_LAUNCH_CHECK("blend3_bwd_kernel");
+  return 0;
+}
+
+}  // namespace smplr
+
+extern "C" {
+
+size_t smplr_blend3_fwd_bytes(int N3) {
+  using namespace smplr;
+  if (N3 <= 0) return 0;
+  return (size_t)((N3 + F3_BN - 1) / F3_BN) * NKT * 9 * 64 * sizeof(uint4);
+}
+
+size_t smplr_blend3_bwd_bytes(int N3) {
+  if (N3 <= 0) return 0;
+  return (size_t)((N3 + 15) / 16) * 7 * 3 * 64 * sizeof(uint4);
+}
+
+int smplr_blend3_pack(const float *blend, int N3, void *pk_fwd, void *pk_bwd, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(N3 > 0, "smplr_blend3_pack: bad size N3=%d", N3);
+  SMPLR_REQUIRE(blend && (pk_fwd || pk_bwd), "smplr_blend3_pack: null pointer");
+  if (pk_fwd) {
+    const int ntile = (N3 + F3_BN - 1) / F3_BN;
+    const size_t n = (size_t)ntile * NKT * 3 * 64;
+    hipLaunchKernelGGL(blend3_pack_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       blend, N3, ntile, reinterpret_cast<uint4 *>(pk_fwd));
+    SMPLR_LAUNCH_CHECK("smplr_blend3_pack(fwd)");
+  }
+  if (pk_bwd) {
+    const int nkt = (N3 + 15) / 16;
+    const size_t n = (size_t)nkt * 7 * 64;
+    hipLaunchKernelGGL(blend3_pack_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       blend, N3, nkt, reinterpret_cast<uint4 *>(pk_bwd));
+    SMPLR_LAUNCH_CHECK("smplr_blend3_pack(bwd)");
+  }
+  return 0;
+}
+
+int smplr_coef3_pack(const float *coef, int B, void *coef3, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0, "smplr_coef3_pack: bad size B=%d", B);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(coef && coef3, "smplr_coef3_pack: null pointer");
+  const int n = (B + 31) / 32 * NKT * 64;
+  hipLaunchKernelGGL(coef3_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), coef, B,
+                     smplr_coef_ld(B), reinterpret_cast<u32x4 *>(coef3));
+  SMPLR_LAUNCH_CHECK("smplr_coef3_pack");
+  return 0;
+}
+
+int smplr_blend3_fwd(const void *coef3, const void *pk_fwd, const float *v_template, int B, int N3,
+                     float *v_posed, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && N3 > 0, "smplr_blend3_fwd: bad sizes B=%d N3=%d", B, N3);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(coef3 && pk_fwd && v_template && v_posed, "smplr_blend3_fwd: null pointer");
+  const int ntiles = (N3 + F3_BN - 1) / F3_BN, ngroups = (B + 127) / 128;
+  hipLaunchKernelGGL(blend3_fwd_kernel, dim3(ntiles, ngroups), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const u32x4 *>(coef3), reinterpret_cast<const u32x4 *>(pk_fwd), v_template, B,
+                     N3, v_posed);
+  SMPLR_LAUNCH_CHECK("smplr_blend3_fwd");
+  return 0;
+}
+
+size_t smplr_blend3_bwd_workspace(int B, int N3) {
+  if (B <= 0 || N3 <= 0) return 0;
+  return smplr::blend3_bwd_geom(B, N3).part_floats * sizeof(float);
+}
+
+int smplr_blend3_bwd(const float *dv_posed, const void *pk_bwd, int B, int N3, float *dcoef,
+                     void *workspace, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && N3 >= 16, "smplr_blend3_bwd: bad sizes B=%d N3=%d (N3 >= 16)", B, N3);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(dv_posed && pk_bwd && dcoef && workspace, "smplr_blend3_bwd: null pointer");
+  int rc = launch_blend3_bwd_partials(dv_posed, pk_bwd, B, N3, reinterpret_cast<float *>(workspace),
+                                      as_stream(stream));
+  if (rc) return rc;
+  const Blend3BwdGeom g = blend3_bwd_geom(B, N3);
+  return launch_blend_bwd_reduce(reinterpret_cast<const float *>(workspace), B, g.nslices, g.nmt, dcoef,
+                                 as_stream(stream));
+}
+
+}  // extern "C"

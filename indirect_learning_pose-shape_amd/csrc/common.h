@@ -46,6 +46,12 @@ struct BlendBwdGeom { int nslices, cols_per_block, nmt; size_t part_floats; };
 BlendBwdGeom blend_bwd_geom(int B, int N3);
 int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B, int N3, float *part,
                               hipStream_t st);
+int launch_blend_bwd_reduce(const float *part, int B, int nslices, int nmt, float *dcoef, hipStream_t st);
+// the same GEMM on the bf16 matrix cores with 3-way split operands (blend3.hip)
+struct Blend3BwdGeom { int nslices, ktps, nmt; size_t part_floats; };
+Blend3BwdGeom blend3_bwd_geom(int B, int N3);
+int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
+                               hipStream_t st);
 int skin_bwd_nblk(int V);
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
@@ -56,6 +62,41 @@ __device__ __forceinline__ unsigned int orderable(float z) {
   z += 0.0f;  // -0 -> +0 so that equal depths compare equal (tf.argmax treats them as ties)
   const unsigned int b = __float_as_uint(z);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// ---- bf16x3: an fp32 number as the exact sum of three bf16 numbers (blend3.hip, pose.hip) ----
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Two fp32 values -> three dwords of packed bf16 pairs (value 0 in the low half).
+struct Split2 { unsigned h, m, l; };
+__device__ __forceinline__ Split2 split2(float x0, float x1) {
+  const f32x2v v = {x0, x1};
+  const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2v r = {x0 - __uint_as_float(hu << 16), x1 - __uint_as_float(hu & 0xffff0000u)};
+  const unsigned mu = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const f32x2v r2 = {r.x - __uint_as_float(mu << 16), r.y - __uint_as_float(mu & 0xffff0000u)};
+  const unsigned lu = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+  return {hu, mu, lu};
+}
+
+struct Frag3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Frag3 split8(const float x[8]) {
+  u32x4 h, m, l;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const Split2 s = split2(x[2 * d], x[2 * d + 1]);
+    h[d] = s.h;
+    m[d] = s.m;
+    l[d] = s.l;
+  }
+  Frag3 f;
+  f.h = __builtin_bit_cast(bf16x8, h);
+  f.m = __builtin_bit_cast(bf16x8, m);
+  f.l = __builtin_bit_cast(bf16x8, l);
+  return f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -101,9 +101,11 @@ __device__ __forceinline__ void rodrigues_bwd(const float t[3], const float dR[9
 __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
     const float *__restrict__ x, int x_stride, int num_cam, int B,
     const float *__restrict__ J_template, const float *__restrict__ J_dirs,
-    const int *__restrict__ parents, float *__restrict__ coef, int ldc, float *__restrict__ Rs_out,
-    float *__restrict__ J_out, float *__restrict__ A_out, float *__restrict__ newJ_out) {
+    const int *__restrict__ parents, float *__restrict__ coef, int ldc, u32x4 *__restrict__ coef3,
+    float *__restrict__ Rs_out, float *__restrict__ J_out, float *__restrict__ A_out,
+    float *__restrict__ newJ_out) {
   __shared__ PoseLds lds[MPB];
+  __shared__ float sCoef[MPB][224];             // this mesh's coefficient column (for the bf16x3 fragments)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.x * MPB + wave;
   const bool live = n < B;
@@ -114,8 +116,9 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
   const float *xr = x + (size_t)(live ? n : 0) * x_stride;
   const float *beta = xr + num_cam + 72;
 
+  float *sc = sCoef[wave];
   if (live) {
-    float *cf = coef + n;                    // k-major: coef[k][n], row stride ldc
+    float *cf = coef ? coef + n : nullptr;   // k-major: coef[k][n], row stride ldc (optional)
     if (lane < 24) {
       float t[3] = {xr[num_cam + 3 * lane], xr[num_cam + 3 * lane + 1], xr[num_cam + 3 * lane + 2]};
       float R[9];
@@ -127,12 +130,19 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
       }
       if (lane >= 1) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
-          cf[(size_t)(10 + 9 * (lane - 1) + e) * ldc] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+        for (int e = 0; e < 9; ++e) {
+          const float pf = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+          sc[10 + 9 * (lane - 1) + e] = pf;
+          if (cf) cf[(size_t)(10 + 9 * (lane - 1) + e) * ldc] = pf;
+        }
       }
     }
-    if (lane < 10) cf[(size_t)lane * ldc] = beta[lane];
-    if (lane >= 10 && lane < 13) cf[(size_t)(207 + lane) * ldc] = 0.0f;  // 217..219
+    if (lane < 10) {
+      sc[lane] = beta[lane];
+      if (cf) cf[(size_t)lane * ldc] = beta[lane];
+    }
+    if (lane >= 10 && lane < 17) sc[207 + lane] = 0.0f;                        // 217..223
+    if (cf && lane >= 10 && lane < 13) cf[(size_t)(207 + lane) * ldc] = 0.0f;  // 217..219
     for (int e = lane; e < 72; e += 64) {
       float acc = J_template[e];
 #pragma unroll
@@ -142,6 +152,19 @@ __global__ __launch_bounds__(MPB * 64) void pose_fwd_kernel(
     }
   }
   wave_sync();
+  if (live && coef3 && lane < 28) {
+    // the same column as bf16x3 MFMA A-fragments (blend3.hip): lane = (k-tile, half) of this mesh's row
+    // of its 32-mesh tile; [mesh tile][k-tile 14][split 3][lane 64] x 16 B
+    const int kt = lane >> 1, hh = lane & 1;
+    float xk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xk[j] = sc[kt * 16 + 8 * hh + j];
+    const Frag3 f = split8(xk);
+    u32x4 *o = coef3 + ((size_t)((n >> 5) * 14 + kt) * 3) * 64 + hh * 32 + (n & 31);
+    o[0] = __builtin_bit_cast(u32x4, f.h);
+    o[64] = __builtin_bit_cast(u32x4, f.m);
+    o[128] = __builtin_bit_cast(u32x4, f.l);
+  }
   // root
   if (live && lane < 12) {
     const int r = lane >> 2, c = lane & 3;
@@ -316,19 +339,20 @@ int smplr_abi_version(void) { return SMPLR_ABI_VERSION; }
 const char *smplr_last_error(void) { return smplr::g_err; }
 
 int smplr_coef_ld(int B) { return B > 0 ? (B + 31) / 32 * 32 : 0; }
+size_t smplr_coef3_bytes(int B) { return B > 0 ? (size_t)((B + 31) / 32) * 14 * 3 * 64 * 16 : 0; }
 
 int smplr_pose_fwd(const float *x, int x_stride, int num_cam, int B, const float *J_template,
-                   const float *J_dirs, const int32_t *parents, float *coef, float *Rs, float *J,
+                   const float *J_dirs, const int32_t *parents, float *coef, void *coef3, float *Rs, float *J,
                    float *A, float *J_transformed, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && num_cam >= 0 && num_cam <= 16 && x_stride >= num_cam + 82,
                 "smplr_pose_fwd: bad sizes B=%d num_cam=%d x_stride=%d", B, num_cam, x_stride);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(x && J_template && J_dirs && parents && coef && Rs && J && A && J_transformed,
+  SMPLR_REQUIRE(x && J_template && J_dirs && parents && (coef || coef3) && Rs && J && A && J_transformed,
                 "smplr_pose_fwd: null pointer");
   hipLaunchKernelGGL(pose_fwd_kernel, dim3((B + MPB - 1) / MPB), dim3(MPB * 64), 0, as_stream(stream),
-                     x, x_stride, num_cam, B, J_template, J_dirs, parents, coef, smplr_coef_ld(B), Rs, J, A,
-                     J_transformed);
+                     x, x_stride, num_cam, B, J_template, J_dirs, parents, coef, smplr_coef_ld(B),
+                     reinterpret_cast<u32x4 *>(coef3), Rs, J, A, J_transformed);
   SMPLR_LAUNCH_CHECK("smplr_pose_fwd");
   return 0;
 }
@@ -354,13 +378,14 @@ static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 size_t smplr_smpl_bwd_workspace(int B, int V) {
   using namespace smplr;
   if (B <= 0 || V <= 0) return 0;
+  const size_t pf = blend_bwd_geom(B, 3 * V).part_floats, pf3 = blend3_bwd_geom(B, 3 * V).part_floats;
   return align256((size_t)B * V * 3 * sizeof(float)) + align256((size_t)B * skin_bwd_nblk(V) * 292 * sizeof(float)) +
-         align256(blend_bwd_geom(B, 3 * V).part_floats * sizeof(float));
+         align256((pf > pf3 ? pf : pf3) * sizeof(float));
 }
 
 int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed, const float *x,
                    int x_stride, int num_cam, int B, int V, int vertex_sampling, const float *blend_t,
-                   const float *lbs_weights, const float *lbs_top4, const float *J_dirs, const int32_t *parents, const float *Rs,
+                   const void *blend3_bwd, const float *lbs_weights, const float *lbs_top4, const float *J_dirs, const int32_t *parents, const float *Rs,
                    const float *J, const float *A, const float *v_posed, float *dx, void *workspace,
                    void *stream) {
   using namespace smplr;
@@ -369,7 +394,8 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_tran
                 "smplr_smpl_bwd: bad sizes B=%d V=%d num_cam=%d x_stride=%d vs=%d", B, V, num_cam, x_stride,
                 vertex_sampling);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(x && blend_t && lbs_weights && J_dirs && parents && Rs && J && A && v_posed && dx && workspace,
+  SMPLR_REQUIRE(!blend3_bwd || V >= 6, "smplr_smpl_bwd: the bf16x3 GEMM needs 3V >= 16");
+  SMPLR_REQUIRE(x && (blend_t || blend3_bwd) && lbs_weights && J_dirs && parents && Rs && J && A && v_posed && dx && workspace,
                 "smplr_smpl_bwd: null pointer");
   SMPLR_REQUIRE(dverts || dproj, "smplr_smpl_bwd: need dverts and/or dproj");
   SMPLR_REQUIRE(!dproj || (num_cam >= 4), "smplr_smpl_bwd: dproj needs the 4 camera columns");
@@ -382,12 +408,22 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_tran
   int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, lbs_top4, A, dproj ? x : nullptr, x_stride, B, V,
                                     vertex_sampling, dv_posed, skin_part, st);
   if (rc) return rc;
-  rc = launch_blend_bwd_partials(dv_posed, blend_t, B, 3 * V, blend_part, st);
+  int nslices, nmt;
+  if (blend3_bwd) {                              // bf16x3 operands (blend3.hip); else the fp32 matrix-core GEMM
+    rc = launch_blend3_bwd_partials(dv_posed, blend3_bwd, B, 3 * V, blend_part, st);
+    const Blend3BwdGeom g3 = blend3_bwd_geom(B, 3 * V);
+    nslices = g3.nslices;
+    nmt = g3.nmt;
+  } else {
+    rc = launch_blend_bwd_partials(dv_posed, blend_t, B, 3 * V, blend_part, st);
+    const BlendBwdGeom g = blend_bwd_geom(B, 3 * V);
+    nslices = g.nslices;
+    nmt = g.nmt;
+  }
   if (rc) return rc;
-  const BlendBwdGeom g = blend_bwd_geom(B, 3 * V);
   hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(PBW), 0, st, x, x_stride, num_cam, B,
                      J_dirs, parents, Rs, J, A, (const float *)nullptr, (const float *)nullptr, dJ_transformed,
-                     (const float *)nullptr, dx, skin_part, skin_bwd_nblk(V), blend_part, g.nslices, g.nmt,
+                     (const float *)nullptr, dx, skin_part, skin_bwd_nblk(V), blend_part, nslices, nmt,
                      dproj ? 1 : 0);
   SMPLR_LAUNCH_CHECK("smplr_smpl_bwd(pose)");
   return 0;

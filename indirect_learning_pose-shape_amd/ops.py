@@ -39,6 +39,10 @@ class SMPLConstants:
     parents: torch.Tensor       # (24,) int32
     joint_regressor: Optional[torch.Tensor] = None   # (V,19|14) cocoplus / lsp, optional
     lbs_top4: Optional[torch.Tensor] = None   # (V,8) sparse form [w0..w3 | j0..j3] when every row has <= 4 non-zeros
+    # blend split into three bf16 terms per entry, in MFMA fragment order (smplr_blend3_pack): the operands of
+    # the bf16x3 blend GEMMs, the default on a HIP device; None = the fp32 matrix-core GEMMs (blend / blend_t)
+    blend3_fwd: Optional[torch.Tensor] = None
+    blend3_bwd: Optional[torch.Tensor] = None
 
     @staticmethod
     def from_model(model: SMPLModelData, device, joint_type: str = "lsp") -> "SMPLConstants":
@@ -68,11 +72,41 @@ class SMPLConstants:
             if joint_type == "lsp":
                 jr = jr[:, :14]                                             # :86-87
             jr = f32(jr)
-        return SMPLConstants(
+        c = SMPLConstants(
             V=V, v_template=f32(np.asarray(model.v_template).reshape(-1)), blend=f32(blend),
             blend_t=f32(blend_t), J_template=f32(J_template), J_dirs=f32(J_dirs), lbs_weights=f32(model.weights), lbs_top4=top4,
             parents=torch.as_tensor(np.asarray(model.parents, np.int32)).to(device),
             joint_regressor=jr)
+        if c.blend.is_cuda and blend_gemm_mode() == "bf16x3":
+            c.pack_blend3()
+        return c
+
+    def pack_blend3(self):
+        """Split + lay out the blend constant for the bf16x3 GEMMs (one-off, on the device)."""
+        lib = _lib.load()
+        N3 = 3 * self.V
+        dev = self.blend.device
+        self.blend3_fwd = torch.empty(lib.smplr_blend3_fwd_bytes(N3), dtype=torch.uint8, device=dev)
+        self.blend3_bwd = torch.empty(lib.smplr_blend3_bwd_bytes(N3), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.smplr_blend3_pack(ptr(self.blend), N3, ptr(self.blend3_fwd), ptr(self.blend3_bwd), stream()),
+                  "smplr_blend3_pack")
+        return self
+
+    def fp32_gemm(self):
+        """A view of the same constants that runs the blend GEMMs on the fp32 matrix cores."""
+        import dataclasses
+        return dataclasses.replace(self, blend3_fwd=None, blend3_bwd=None)
+
+
+def blend_gemm_mode() -> str:
+    """'bf16x3' (default): blend GEMMs on the bf16 matrix cores with 3-way split, fp32-grade operands;
+    'f32': v_mfma_f32_32x32x2_f32.  Chosen when the constants are uploaded (env SMPLR_BLEND_GEMM)."""
+    import os
+    m = os.environ.get("SMPLR_BLEND_GEMM", "bf16x3").lower()
+    if m not in ("bf16x3", "f32"):
+        raise RuntimeError("SMPLR_BLEND_GEMM must be bf16x3 or f32, got %r" % m)
+    return m
 
 
 @dataclass
@@ -116,29 +150,51 @@ def _workspace(nbytes, like):
 
 
 # --------------------------------------------------------------------------- raw stage calls
-def _pose_fwd(x, num_cam, c: SMPLConstants, out=None):
+class PoseCoef:
+    """The blend GEMM's per-step operand as smplr_pose_fwd writes it: `kmajor` (220, ld) fp32 for the fp32
+    matrix-core GEMM and/or `frag3`, the same columns as bf16x3 MFMA fragments for smplr_blend3_fwd."""
+    __slots__ = ("kmajor", "frag3", "B")
+
+    def __init__(self, kmajor, frag3, B):
+        self.kmajor, self.frag3, self.B = kmajor, frag3, B
+
+
+def _pose_fwd(x, num_cam, c: SMPLConstants, out=None, want=None):
+    """want: 'frag3' | 'kmajor' | 'both'; default = what the constants' blend GEMM reads."""
     lib = _lib.load()
     B = x.shape[0]
     if out is None:
         out = (None, _empty((B, 24, 9), x), _empty((B, 24, 3), x), _empty((B, 24, 12), x), _empty((B, 24, 3), x))
-    coef, Rs, J, A, Jt = out
-    if coef is None:        # k-major (220, ld): the layout the blend GEMM's matrix cores read directly
-        coef = _empty((KPAD, lib.smplr_coef_ld(B)), x)
+    _, Rs, J, A, Jt = out
+    if want is None:
+        want = "frag3" if c.blend3_fwd is not None else "kmajor"
+    km = _empty((KPAD, lib.smplr_coef_ld(B)), x) if want in ("kmajor", "both") else None
+    f3 = (torch.empty(max(int(lib.smplr_coef3_bytes(B)), 16), dtype=torch.uint8, device=x.device)
+          if want in ("frag3", "both") else None)
     check(lib.smplr_pose_fwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_template), ptr(c.J_dirs),
-                             ptr(c.parents), ptr(coef), ptr(Rs), ptr(J), ptr(A), ptr(Jt), stream()),
+                             ptr(c.parents), ptr(km), ptr(f3), ptr(Rs), ptr(J), ptr(A), ptr(Jt), stream()),
           "smplr_pose_fwd")
-    return coef, Rs, J, A, Jt
+    return PoseCoef(km, f3, B), Rs, J, A, Jt
 
 
-def _blend_fwd(coef, c: SMPLConstants, B, out=None):
-    """coef: (220, smplr_coef_ld(B)) k-major, as _pose_fwd returns it, for B meshes."""
+def _blend_fwd(coef: PoseCoef, c: SMPLConstants, B, out=None):
+    """coef: what _pose_fwd returned for the same B meshes."""
     lib = _lib.load()
-    if tuple(coef.shape) != (KPAD, lib.smplr_coef_ld(B)):
-        raise RuntimeError("coef must be (%d, %d) for %d meshes, got %s"
-                           % (KPAD, lib.smplr_coef_ld(B), B, tuple(coef.shape)))
-    v_posed = _empty((B, c.V, 3), coef) if out is None else out
-    check(lib.smplr_blend_fwd(ptr(coef), ptr(c.blend), ptr(c.v_template), B, 3 * c.V, ptr(v_posed),
-                              stream()), "smplr_blend_fwd")
+    if coef.B != B:
+        raise RuntimeError("coef was computed for %d meshes, not %d" % (coef.B, B))
+    v_posed = _empty((B, c.V, 3), c.v_template) if out is None else out
+    if c.blend3_fwd is not None:
+        if coef.frag3 is None:                    # k-major only: split it here (smplr_coef3_pack)
+            coef.frag3 = torch.empty(max(int(lib.smplr_coef3_bytes(B)), 16), dtype=torch.uint8,
+                                     device=v_posed.device)
+            check(lib.smplr_coef3_pack(ptr(coef.kmajor), B, ptr(coef.frag3), stream()), "smplr_coef3_pack")
+        check(lib.smplr_blend3_fwd(ptr(coef.frag3), ptr(c.blend3_fwd), ptr(c.v_template), B, 3 * c.V, ptr(v_posed),
+                                   stream()), "smplr_blend3_fwd")
+    else:
+        if coef.kmajor is None:
+            raise RuntimeError("the fp32 blend GEMM needs the k-major coef (_pose_fwd(..., want='kmajor'))")
+        check(lib.smplr_blend_fwd(ptr(coef.kmajor), ptr(c.blend), ptr(c.v_template), B, 3 * c.V, ptr(v_posed),
+                                  stream()), "smplr_blend_fwd")
     return v_posed
 
 
@@ -168,7 +224,7 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
         dx.zero_()
     ws = _workspace(lib.smplr_smpl_bwd_workspace(B, c.V), x)
     check(lib.smplr_smpl_bwd(ptr(dverts), ptr(dproj), ptr(dJt), ptr(x), x.shape[1], num_cam, B, c.V, vs,
-                             ptr(c.blend_t), ptr(c.lbs_weights), ptr(c.lbs_top4), ptr(c.J_dirs), ptr(c.parents),
+                             ptr(c.blend_t), ptr(c.blend3_bwd), ptr(c.lbs_weights), ptr(c.lbs_top4), ptr(c.J_dirs), ptr(c.parents),
                              ptr(Rs), ptr(J),
                              ptr(A), ptr(v_posed), ptr(dx), ptr(ws), stream()), "smplr_smpl_bwd")
     return dx

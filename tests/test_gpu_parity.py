@@ -345,14 +345,17 @@ def test_joints_output(layer, smpl_model):
     assert np.abs(j.cpu().numpy() - want).max() < 1e-5
 
 
-def test_granular_backward_chain_equals_fused(smpl_model):
-    """smplr_skin_bwd -> smplr_blend_bwd -> smplr_pose_bwd (the stand-alone entry points) give the same
-    dx as the fused smplr_smpl_bwd the autograd nodes use."""
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+def test_granular_backward_chain_equals_fused(smpl_model, gemm):
+    """smplr_skin_bwd -> smplr_blend(3)_bwd -> smplr_pose_bwd (the stand-alone entry points) give the same
+    dx as the fused smplr_smpl_bwd the autograd nodes use, with either blend GEMM."""
     from ilps_amd import ops, _lib
     from ilps_amd._lib import ptr, stream, check
     lib = _lib.load()
     d = dev()
-    c = ops.SMPLConstants.from_model(smpl_model, d)
+    c = ops.SMPLConstants.from_model(smpl_model, d).pack_blend3()
+    if gemm == "f32":
+        c = c.fp32_gemm()
     B, V = 37, c.V
     x = t(make_x(B, 48, seed=91))
     coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
@@ -366,13 +369,101 @@ def test_granular_backward_chain_equals_fused(smpl_model):
                              86, B, V, 1,
                              ptr(dv_posed), ptr(dA), ptr(dcam), ptr(ws), stream()), "skin_bwd")
     dcoef = torch.empty(B, 220, device=d)
-    ws2 = torch.empty(lib.smplr_blend_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
-    check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend_t), B, 3 * V, ptr(dcoef), ptr(ws2), stream()), "blend_bwd")
+    if gemm == "f32":
+        ws2 = torch.empty(lib.smplr_blend_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
+        check(lib.smplr_blend_bwd(ptr(dv_posed), ptr(c.blend_t), B, 3 * V, ptr(dcoef), ptr(ws2), stream()), "blend_bwd")
+    else:
+        ws2 = torch.empty(lib.smplr_blend3_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
+        check(lib.smplr_blend3_bwd(ptr(dv_posed), ptr(c.blend3_bwd), B, 3 * V, ptr(dcoef), ptr(ws2), stream()),
+              "blend3_bwd")
     dx = torch.empty(B, 86, device=d)
     check(lib.smplr_pose_bwd(ptr(x), 86, 4, B, ptr(c.J_dirs), ptr(c.parents), ptr(Rs), ptr(J), ptr(A), ptr(dcoef),
                              ptr(dA), ptr(dJt), ptr(dcam), ptr(dx), stream()), "pose_bwd")
     torch.cuda.synchronize()
     assert torch.equal(dx, fused)          # same kernels, same summation order
+
+
+@pytest.mark.parametrize("B", [1, 37, 128, 200])
+def test_blend3_matches_fp32_path(smpl_model, B):
+    """The bf16x3 blend GEMMs (three bf16 terms per fp32 operand, six partial products, fp32 accumulation)
+    against float64 and against the fp32 matrix-core GEMMs on the same operands, forward and backward.
+    Bars: v_posed within 2e-6 abs of float64 (the vertex bar is 1e-4) and no worse than 4x the fp32 path's own
+    error; dcoef within 2e-6 of max|dcoef| and no worse than 4x the fp32 path's error."""
+    from ilps_amd import ops, _lib
+    from ilps_amd._lib import ptr, stream, check
+    lib = _lib.load()
+    d = dev()
+    c3 = ops.SMPLConstants.from_model(smpl_model, d).pack_blend3()
+    c1 = c3.fp32_gemm()
+    assert c3.blend3_fwd is not None and c1.blend3_fwd is None
+    V = c3.V
+    x = t(make_x(B, 48, seed=400 + B))
+    coef = ops._pose_fwd(x, 4, c3, want="both")[0]
+    vp3 = ops._blend_fwd(coef, c3, B)
+    vp1 = ops._blend_fwd(coef, c1, B)
+    # the fragments pose_fwd writes are the ones smplr_coef3_pack makes from the k-major columns (live rows)
+    f3 = torch.empty_like(coef.frag3)
+    check(lib.smplr_coef3_pack(ptr(coef.kmajor), B, ptr(f3), stream()), "coef3_pack")
+    rows = torch.arange(64, device=d) % 32 + 32 * (torch.arange((B + 31) // 32, device=d)[:, None, None, None])
+    live = (rows < B).expand(-1, 14, 3, -1)
+    assert torch.equal(coef.frag3.view(-1, 14, 3, 64, 16)[live], f3.view(-1, 14, 3, 64, 16)[live])
+    blend64 = c3.blend.cpu().numpy().astype(np.float64)
+    ref = coef.kmajor.cpu().numpy().astype(np.float64)[:, :B].T @ blend64 + c3.v_template.cpu().numpy().astype(np.float64)
+    e3 = np.abs(vp3.cpu().numpy().reshape(B, -1) - ref).max()
+    e1 = np.abs(vp1.cpu().numpy().reshape(B, -1) - ref).max()
+    assert e3 <= 2e-6 and e3 <= 4 * e1 + 1e-7, "forward: bf16x3 %.3e, fp32 %.3e" % (e3, e1)
+    # backward: dcoef = dv_posed x blend^T
+    rng = np.random.default_rng(B)
+    g = t(rng.normal(0, 1, (B, V, 3)))
+    dc3, dc1 = torch.empty(B, 220, device=d), torch.empty(B, 220, device=d)
+    ws3 = torch.empty(lib.smplr_blend3_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
+    ws1 = torch.empty(lib.smplr_blend_bwd_workspace(B, 3 * V) // 4 + 1, device=d)
+    check(lib.smplr_blend3_bwd(ptr(g), ptr(c3.blend3_bwd), B, 3 * V, ptr(dc3), ptr(ws3), stream()), "blend3_bwd")
+    check(lib.smplr_blend_bwd(ptr(g), ptr(c1.blend_t), B, 3 * V, ptr(dc1), ptr(ws1), stream()), "blend_bwd")
+    refb = g.cpu().numpy().astype(np.float64).reshape(B, -1) @ blend64.T
+    scale = np.abs(refb).max()
+    b3 = np.abs(dc3.cpu().numpy() - refb).max() / scale
+    b1 = np.abs(dc1.cpu().numpy() - refb).max() / scale
+    assert b3 <= 2e-6 and b3 <= 4 * b1 + 1e-7, "backward: bf16x3 %.3e, fp32 %.3e" % (b3, b1)
+
+
+def test_blend3_wide_dynamic_range():
+    """Operands spread over 12 decades and a matrix whose column count is neither a multiple of 96 nor of 16:
+    the three-term split must stay fp32-grade per product (error relative to sum |a||b|), and the ragged tiles
+    must be exact zeros where the matrix ends."""
+    from ilps_amd import _lib
+    from ilps_amd._lib import ptr, stream, check
+    lib = _lib.load()
+    d = dev()
+    rng = np.random.default_rng(77)
+    B, N3 = 45, 1000 * 3 + 1
+    blend = (rng.normal(0, 1, (220, N3)) * 10.0 ** rng.uniform(-6, 6, (220, N3))).astype(np.float32)
+    blend[217:] = 0
+    ld = lib.smplr_coef_ld(B)
+    coef = np.zeros((220, ld), np.float32)
+    coef[:, :B] = (rng.normal(0, 1, (220, B)) * 10.0 ** rng.uniform(-6, 6, (220, B))).astype(np.float32)
+    vt = rng.normal(0, 1, N3).astype(np.float32)
+    bl, cf, vtd = t(blend), t(coef), t(vt)
+    pf = torch.empty(lib.smplr_blend3_fwd_bytes(N3), dtype=torch.uint8, device=d)
+    pb = torch.empty(lib.smplr_blend3_bwd_bytes(N3), dtype=torch.uint8, device=d)
+    check(lib.smplr_blend3_pack(ptr(bl), N3, ptr(pf), ptr(pb), stream()), "pack")
+    out = torch.empty(B, N3, device=d)
+    c3 = torch.empty(lib.smplr_coef3_bytes(B), dtype=torch.uint8, device=d)
+    check(lib.smplr_coef3_pack(ptr(cf), B, ptr(c3), stream()), "coef3_pack")
+    check(lib.smplr_blend3_fwd(ptr(c3), ptr(pf), ptr(vtd), B, N3, ptr(out), stream()), "blend3_fwd")
+    a64, b64 = coef[:, :B].astype(np.float64).T, blend.astype(np.float64)
+    ref = a64 @ b64 + vt
+    mag = np.abs(a64) @ np.abs(b64) + np.abs(vt)
+    assert (np.abs(out.cpu().numpy() - ref) / mag).max() <= 2e-6
+    g = rng.normal(0, 1, (B, N3)).astype(np.float32)
+    dc = torch.empty(B, 220, device=d)
+    ws = torch.empty(lib.smplr_blend3_bwd_workspace(B, N3) // 4 + 1, device=d)
+    check(lib.smplr_blend3_bwd(ptr(t(g)), ptr(pb), B, N3, ptr(dc), ptr(ws), stream()), "blend3_bwd")
+    refb = g.astype(np.float64) @ b64.T
+    magb = np.abs(g.astype(np.float64)) @ np.abs(b64.T) + 1e-30
+    got = dc.cpu().numpy()
+    assert (np.abs(got - refb) / magb)[:, :217].max() <= 4e-6
+    assert np.all(got[:, 217:] == 0)
 
 
 def test_sparse_and_dense_skinning_bit_identical(smpl_model):
