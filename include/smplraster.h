@@ -133,10 +133,16 @@ int smplr_skin_bwd(const float *dverts, const float *dproj,
  * smplr_pose_bwd in three launches, the partial sums of the first two folded into the third
  * (fixed summation order).  Same semantics as chaining the three entry points above.
  * The blend GEMM uses blend3_bwd (smplr_blend3_pack's pk_bwd) when it is not NULL, else blend_t.
+ * seg_part / seg_vslot / seg_nsplit (NULL, NULL, 0 to omit): the segmentation rasteriser's gradient as
+ * smplr_seg_bwd leaves it when called with dproj = NULL - per-row-block slot sums in its workspace - plus
+ * the vertex -> slot map of the forward and smplr_seg_bwd_nsplit(W).  The skinning backward then gathers
+ * d(seg)/d(proj) by vertex, summing the row blocks in the order the merge kernel would have (bit-identical),
+ * and adds it to dproj (if given): one launch and one (B,VP,3) round trip less.
  * workspace: smplr_smpl_bwd_workspace(B,V) bytes.                                              */
 size_t smplr_smpl_bwd_workspace(int B, int V);
-int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed,
-                   const float *x, int x_stride, int num_cam, int B, int V, int vertex_sampling,
+int smplr_smpl_bwd(const float *dverts, const float *dproj,
+                   const float *seg_part, const int16_t *seg_vslot, int seg_nsplit,
+                   const float *dJ_transformed, const float *x, int x_stride, int num_cam, int B, int V, int vertex_sampling,
                    const float *blend_t, const void *blend3_bwd,
                    const float *lbs_weights, const float *lbs_top4,
                    const float *J_dirs, const int32_t *parents, const float *Rs, const float *J, const float *A,
@@ -173,24 +179,30 @@ int smplr_visibility(const float *proj, int B, int VP, int grid_wh, int ref_comp
  * arg (B,W,W,32) int16, slot = channel: [0] = 1 iff 0 <= sum_p <= 1 (the clip's pass-through
  *   gate); [1+p] = index into rec[b] of the maximising vertex of part p, or -1 when no vertex
  *   contributes a non-zero score.  rec + arg are what the backward needs (no proj/mask/seg).
+ * vslot (B,VP) int16 or NULL: for each vertex position its slot in rec[b], -1 if it has no record
+ *   (needed only by the gather form of the backward, see smplr_smpl_bwd).
  * Requires P <= 31, VP <= 32767, W <= 160.                                                     */
 int smplr_seg_slots(int P, int K);
 size_t smplr_seg_workspace(int B, int VP, int W, int P, int K);
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W,
                   const int32_t *part_pos, const int32_t *part_off, int P, int K,
-                  void *workspace, float *seg, int16_t *arg, float *rec, void *stream);
+                  void *workspace, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream);
 
 /* compute_mask + projects_to_seg in one call (the model.py:113-118 pair as the fused decoder
  * runs it): same results as smplr_visibility followed by smplr_seg_fwd, the z-buffer being built
  * inside the binning workgroup; mask (B,VP) is an OUTPUT here.  Same workspace as smplr_seg_fwd. */
 int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int ref_compat,
                       const int32_t *part_pos, const int32_t *part_off, int P, int K,
-                      void *workspace, float *mask, float *seg, int16_t *arg, float *rec, void *stream);
+                      void *workspace, float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot,
+                      void *stream);
 
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:
  * NaN).  The score is recomputed from the arg-min record, so seg itself is not an input.
- * workspace: smplr_seg_bwd_workspace(B,W) bytes (per-row-block partial sums, merged in order). */
+ * workspace: smplr_seg_bwd_workspace(B,W) bytes (per-row-block partial sums, merged in order).
+ * dproj = NULL stops after the partial sums: the workspace (B, smplr_seg_bwd_nsplit(W), 5, 4096, 2) then IS
+ * the result, to be handed to smplr_smpl_bwd together with the forward's vslot.                   */
+int smplr_seg_bwd_nsplit(int W);
 size_t smplr_seg_bwd_workspace(int B, int W);
 int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
                   int B, int VP, int W, int P, int K, float *dproj, void *workspace, void *stream);

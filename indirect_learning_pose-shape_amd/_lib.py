@@ -43,14 +43,15 @@ SIGNATURES = {
     "smplr_skin_bwd_workspace": (c_size_t, [I, I]),
     "smplr_skin_bwd": (c_int, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "smplr_smpl_bwd_workspace": (c_size_t, [I, I]),
-    "smplr_smpl_bwd": (c_int, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "smplr_smpl_bwd": (c_int, [P, P, P, P, I, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "smplr_project_fwd": (c_int, [P, P, I, I, I, I, P, P]),
     "smplr_project_bwd": (c_int, [P, P, P, I, I, I, I, P, P, P]),
     "smplr_visibility": (c_int, [P, I, I, I, I, P, P]),
     "smplr_seg_workspace": (c_size_t, [I, I, I, I, I]),
     "smplr_seg_slots": (c_int, [I, I]),
-    "smplr_seg_fwd": (c_int, [P, P, I, I, I, P, P, I, I, P, P, P, P, P]),
-    "smplr_vis_seg_fwd": (c_int, [P, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P]),
+    "smplr_seg_fwd": (c_int, [P, P, I, I, I, P, P, I, I, P, P, P, P, P, P]),
+    "smplr_vis_seg_fwd": (c_int, [P, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P, P]),
+    "smplr_seg_bwd_nsplit": (c_int, [I]),
     "smplr_seg_bwd_workspace": (c_size_t, [I, I]),
     "smplr_seg_bwd": (c_int, [P, P, P, I, I, I, I, I, P, P, P]),
     "smplr_silh_workspace": (c_size_t, [I, I, I]),

@@ -53,7 +53,14 @@ Blend3BwdGeom blend3_bwd_geom(int B, int N3);
 int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
                                hipStream_t st);
 int skin_bwd_nblk(int V);
-int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
+// The segmentation backward's per-row-block slot sums (raster.hip), which the skinning backward can gather
+// by vertex instead of reading a merged dproj: part (B, nsplit, SB_NWIN, SB_SLOTS, 2), vslot (B, VP) = the
+// record slot of each vertex (-1: none), nsplit = ceil(W / SB_ROWS).
+constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators per window
+constexpr int SB_NWIN = 5;       // slot windows the partial buffer holds: S <= 20480
+constexpr int SB_ROWS = 8;       // rows (strips) per block
+struct SegGrad { const float *part; const int16_t *vslot; int nsplit; };
+int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
                              int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st);
 

@@ -383,7 +383,8 @@ size_t smplr_smpl_bwd_workspace(int B, int V) {
          align256((pf > pf3 ? pf : pf3) * sizeof(float));
 }
 
-int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_transformed, const float *x,
+int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *seg_part, const int16_t *seg_vslot,
+                   int seg_nsplit, const float *dJ_transformed, const float *x,
                    int x_stride, int num_cam, int B, int V, int vertex_sampling, const float *blend_t,
                    const void *blend3_bwd, const float *lbs_weights, const float *lbs_top4, const float *J_dirs, const int32_t *parents, const float *Rs,
                    const float *J, const float *A, const float *v_posed, float *dx, void *workspace,
@@ -397,16 +398,20 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_tran
   SMPLR_REQUIRE(!blend3_bwd || V >= 6, "smplr_smpl_bwd: the bf16x3 GEMM needs 3V >= 16");
   SMPLR_REQUIRE(x && (blend_t || blend3_bwd) && lbs_weights && J_dirs && parents && Rs && J && A && v_posed && dx && workspace,
                 "smplr_smpl_bwd: null pointer");
-  SMPLR_REQUIRE(dverts || dproj, "smplr_smpl_bwd: need dverts and/or dproj");
-  SMPLR_REQUIRE(!dproj || (num_cam >= 4), "smplr_smpl_bwd: dproj needs the 4 camera columns");
+  SMPLR_REQUIRE((seg_part != nullptr) == (seg_vslot != nullptr) && (!seg_part || seg_nsplit > 0),
+                "smplr_smpl_bwd: seg_part, seg_vslot and seg_nsplit go together");
+  const bool has_proj = dproj || seg_part;
+  SMPLR_REQUIRE(dverts || has_proj, "smplr_smpl_bwd: need dverts and/or dproj / the segmentation slot sums");
+  SMPLR_REQUIRE(!has_proj || (num_cam >= 4), "smplr_smpl_bwd: dproj needs the 4 camera columns");
   hipStream_t st = as_stream(stream);
   char *base = reinterpret_cast<char *>(workspace);
   float *dv_posed = reinterpret_cast<float *>(base);
   float *skin_part = reinterpret_cast<float *>(base + align256((size_t)B * V * 3 * sizeof(float)));
   float *blend_part = reinterpret_cast<float *>(reinterpret_cast<char *>(skin_part) +
                                                 align256((size_t)B * skin_bwd_nblk(V) * 292 * sizeof(float)));
-  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, lbs_top4, A, dproj ? x : nullptr, x_stride, B, V,
-                                    vertex_sampling, dv_posed, skin_part, st);
+  int rc = launch_skin_bwd_partials(dverts, dproj, SegGrad{seg_part, seg_vslot, seg_nsplit}, v_posed, lbs_weights,
+                                    lbs_top4, A, has_proj ? x : nullptr, x_stride, B, V, vertex_sampling, dv_posed,
+                                    skin_part, st);
   if (rc) return rc;
   int nslices, nmt;
   if (blend3_bwd) {                              // bf16x3 operands (blend3.hip); else the fp32 matrix-core GEMM
@@ -424,7 +429,7 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *dJ_tran
   hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(PBW), 0, st, x, x_stride, num_cam, B,
                      J_dirs, parents, Rs, J, A, (const float *)nullptr, (const float *)nullptr, dJ_transformed,
                      (const float *)nullptr, dx, skin_part, skin_bwd_nblk(V), blend_part, nslices, nmt,
-                     dproj ? 1 : 0);
+                     has_proj ? 1 : 0);
   SMPLR_LAUNCH_CHECK("smplr_smpl_bwd(pose)");
   return 0;
 }

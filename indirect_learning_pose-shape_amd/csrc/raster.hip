@@ -110,7 +110,8 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
                                                         const int *__restrict__ part_off, int P, int K,
                                                         int VP, int W, int S, float4 *__restrict__ G,
                                                         int *__restrict__ goff, int *__restrict__ lstart,
-                                                        uint2 *__restrict__ lrec, int vgrid, int ref_compat) {
+                                                        uint2 *__restrict__ lrec, int vgrid, int ref_compat,
+                                                        short *__restrict__ vslot) {
   // (16-B aligned: the 64-bit z-buffer keys behind the counters need 8, whatever the static LDS in front)
   extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // npix | VIS: z-buffer keys, visible flags | STAGE: u[VP], v[VP]
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
@@ -123,6 +124,8 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(s_cnt + ((npix + 1) & ~1));
   unsigned int *vis = reinterpret_cast<unsigned int *>(zbuf + cells);
   float *sU = reinterpret_cast<float *>(vis + words), *sV = sU + VP;
+  // vertex -> record slot (for the backward's gather by vertex), staged here and copied out at the end
+  short *sSlot = reinterpret_cast<short *>(sU + (STAGE ? 2 * VP : 0));
 
   // ---- every global operand of the block, requested up front
   const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
@@ -144,6 +147,8 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   if (tid <= P) s_poff[tid] = part_off[tid];
   if (tid == 0) { s_nonunit = 0; s_any_empty = 0; }
   for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
+  if (vslot)                                                  // block-uniform
+    for (int i = tid; i < VP; i += BIN_T) sSlot[i] = -1;
   if (VIS) {
     for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
     for (int i = tid; i < words; i += BIN_T) vis[i] = 0u;
@@ -292,12 +297,15 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       while (k >= s_poff[p + 1]) ++p;
       const Slot s = sl[j];
       if (s.cls == 1) {
-        Gn[s_gpad[p] + (run - s_gstart[p])] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
+        const int slot = s_gpad[p] + (run - s_gstart[p]);
+        Gn[slot] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
+        if (vslot) sSlot[s.pos] = (short)slot;
         ++run;
       } else if (s.cls == 2) {
         const int dst = atomicAdd(&s_cnt[s.pix], 1);
         lrecn[dst] = make_uint2(__float_as_uint(s.x), (unsigned)p);
         Gn[s_gpad[P] + dst] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
+        if (vslot) sSlot[s.pos] = (short)(s_gpad[P] + dst);
       }
     }
   }
@@ -310,6 +318,11 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     const int cnt = s_gstart[tid + 1] - s_gstart[tid];
     for (int i = s_gpad[tid] + cnt; i < s_gpad[tid + 1]; ++i)
       Gn[i] = make_float4(INFINITY, INFINITY, 1.0f, __int_as_float(-1));
+  }
+  if (vslot) {                                                // block-uniform
+    __syncthreads();
+    short *vo = vslot + (size_t)n * VP;
+    for (int i = tid; i < VP; i += BIN_T) vo[i] = sSlot[i];
   }
 }
 
@@ -589,9 +602,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
 // global atomic).  A mesh with more than SB_SLOTS records (only when most vertices are marked
 // visible) is walked once per window of SB_SLOTS slots.  Run-to-run differences are confined to
 // the order in which a block's strips reach a slot's LDS accumulator (last-ulp rounding).
-constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators
-constexpr int SB_NWIN = 5;       // slot windows the partial buffer holds: S <= 20480
-constexpr int SB_ROWS = 8;       // rows (strips) per block
+// (SB_SLOTS = 4096 accumulators per window, SB_NWIN = 5 windows, SB_ROWS = 8 rows per block: common.h)
 constexpr int SB_U = 8;          // pixels in flight per lane
 
 __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float sy) {
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
   const int n = blockIdx.y, tid = threadIdx.x;
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
-  {
+  if (dproj) {                                                // (NULL: the consumer gathers the slot sums itself)
     // this block's share of the mesh's dproj rows := 0 (the merge kernel then stores the sums)
     float *dp = dproj + (size_t)n * VP * 3;
     const int tot = VP * 3, per = (tot + gridDim.x - 1) / gridDim.x;
@@ -1086,7 +1097,7 @@ size_t smplr_seg_workspace(int B, int VP, int W, int P, int K) {
 namespace smplr {
 static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fuse_vis, int grid_wh, int ref_compat,
                         int B, int VP, int W, const int32_t *part_pos, const int32_t *part_off, int P, int K,
-                        void *workspace, float *seg, int16_t *arg, float *rec, void *stream) {
+                        void *workspace, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
                 "%s: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, VP, W, P, K);
   SMPLR_REQUIRE(!fuse_vis || (grid_wh > 0 && grid_wh <= 128), "%s: bad grid_wh=%d (max 128)", fn, grid_wh);
@@ -1104,14 +1115,18 @@ static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fus
   size_t lds = (size_t)((W * W + 1) & ~1) * sizeof(int);
   if (fuse_vis) lds += (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
   SMPLR_REQUIRE(lds <= 150 * 1024, "%s: pixel counters + grid + flags need %zu B of LDS (max 153600)", fn, lds);
-  const bool stage = lds + (size_t)VP * 8 <= 150 * 1024;
+  const size_t slot_lds = vslot ? ((size_t)VP * 2 + 15) / 16 * 16 : 0;
+  SMPLR_REQUIRE(lds + slot_lds <= 150 * 1024, "%s: LDS budget exceeded (%zu B)", fn, lds + slot_lds);
+  const bool stage = lds + slot_lds + (size_t)VP * 8 <= 150 * 1024;
   if (stage) lds += (size_t)VP * 8;
+  lds += slot_lds;
 #define SMPLR_BIN_LAUNCH(VIS_, STAGE_)                                                                        \
   {                                                                                                           \
     int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<VIS_, STAGE_>), lds);                 \
     if (rc) return rc;                                                                                        \
     hipLaunchKernelGGL((seg_bin_kernel<VIS_, STAGE_>), dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos,   \
-                       part_off, P, K, VP, W, S, G, goff, lstart, lrec, fuse_vis ? grid_wh : 1, ref_compat);  \
+                       part_off, P, K, VP, W, S, G, goff, lstart, lrec, fuse_vis ? grid_wh : 1, ref_compat,   \
+                       reinterpret_cast<short *>(vslot));                                                     \
   }
   if (fuse_vis && stage) SMPLR_BIN_LAUNCH(true, true)
   else if (fuse_vis) SMPLR_BIN_LAUNCH(true, false)
@@ -1130,17 +1145,19 @@ static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fus
 
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, const int32_t *part_pos,
                   const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,
-                  float *rec, void *stream) {
+                  float *rec, int16_t *vslot, void *stream) {
   return smplr::seg_fwd_impl("smplr_seg_fwd", proj, const_cast<float *>(mask), false, 0, 0, B, VP, W, part_pos,
-                             part_off, P, K, workspace, seg, arg, rec, stream);
+                             part_off, P, K, workspace, seg, arg, rec, vslot, stream);
 }
 
 int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int ref_compat,
                       const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,
-                      float *mask, float *seg, int16_t *arg, float *rec, void *stream) {
+                      float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
   return smplr::seg_fwd_impl("smplr_vis_seg_fwd", proj, mask, true, grid_wh, ref_compat, B, VP, W, part_pos,
-                             part_off, P, K, workspace, seg, arg, rec, stream);
+                             part_off, P, K, workspace, seg, arg, rec, vslot, stream);
 }
+
+int smplr_seg_bwd_nsplit(int W) { return W > 0 ? (W + smplr::SB_ROWS - 1) / smplr::SB_ROWS : 0; }
 
 size_t smplr_seg_bwd_workspace(int B, int W) {
   if (B <= 0 || W <= 0) return 0;
@@ -1154,7 +1171,7 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= 16000,
                 "smplr_seg_bwd: bad sizes B=%d VP=%d W=%d P=%d K=%d", B, VP, W, P, K);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(dseg && arg && rec && dproj && workspace, "smplr_seg_bwd: null pointer");
+  SMPLR_REQUIRE(dseg && arg && rec && workspace, "smplr_seg_bwd: null pointer");
   hipStream_t st = as_stream(stream);
   const int nsplit = (W + SB_ROWS - 1) / SB_ROWS;
   const int S = seg_slots(P, K);
@@ -1162,6 +1179,7 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
   hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(256), 0, st, dseg, reinterpret_cast<const short *>(arg),
                      reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, reinterpret_cast<float *>(workspace));
   SMPLR_LAUNCH_CHECK("smplr_seg_bwd");
+  if (!dproj) return 0;                        // slot sums only: smplr_smpl_bwd gathers them by vertex
   hipLaunchKernelGGL(seg_bwd_merge_kernel, dim3(SB_SLOTS / 256, B), dim3(256), 0, st,
                      reinterpret_cast<const float *>(workspace), reinterpret_cast<const float4 *>(rec), S, VP, nsplit,
                      dproj);

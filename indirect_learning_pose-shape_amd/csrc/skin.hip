@@ -115,7 +115,8 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
     const float *__restrict__ lbs, const float *__restrict__ top4, const float *__restrict__ A,
     const float *__restrict__ cam,
-    int x_stride, int B, int V, int vs, int VP, float *__restrict__ dv_posed, float *__restrict__ part) {
+    int x_stride, int B, int V, int vs, int VP, float *__restrict__ dv_posed, float *__restrict__ part,
+    const float *__restrict__ seg_part, const short *__restrict__ seg_vslot, int seg_nsplit) {
   __shared__ float sG[SKB_T][4];    // g (3) per vertex
   __shared__ float sP[SKB_T][4];    // [v_posed;1]
   __shared__ float sRed[SKB_T / 64][SKB_PART];
@@ -159,11 +160,34 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     const float *d = dverts + ((size_t)n * V + vc) * 3;
     gv0 = d[0]; gv1 = d[1]; gv2 = d[2];
   }
+  const bool has_proj = dproj || seg_vslot;   // block-uniform
   if (dproj) {                                // block-uniform
     const float *d = dproj + ((size_t)n * VP + min(vpi, VP - 1)) * 3;
-    const float *c = cam + (size_t)n * x_stride;
     gp0 = d[0]; gp1 = d[1]; gp2 = d[2];
+  }
+  if (has_proj) {
+    const float *c = cam + (size_t)n * x_stride;
     ck0 = c[0]; ck1 = c[1];
+  }
+  if (seg_vslot) {                            // block-uniform
+    // d(seg)/d(proj) of this vertex = its record slot's sums over the segmentation backward's row blocks,
+    // added in block order (what seg_bwd_merge_kernel would have stored in dproj); one extra hop: slot -> sums
+    const int slot = seg_vslot[(size_t)n * VP + min(vpi, VP - 1)];
+    const int sl = max(slot, 0), win = sl / SB_SLOTS;
+    const float *sp = seg_part + ((size_t)n * seg_nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (sl - win * SB_SLOTS) * 2;
+    float sx = 0.0f, sy = 0.0f;
+    for (int s0 = 0; s0 < seg_nsplit; s0 += 8) {
+      float2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        t[u] = *reinterpret_cast<const float2 *>(sp + (size_t)min(s0 + u, seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        sx += (s0 + u < seg_nsplit) ? t[u].x : 0.0f;
+        sy += (s0 + u < seg_nsplit) ? t[u].y : 0.0f;
+      }
+    }
+    if (slot >= 0) { gp0 += sx; gp1 += sy; }
   }
   if (tid < 72) sAj[tid] = aj;
   __syncthreads();
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
     if (live) {
       g0 = gv0; g1 = gv1; g2 = gv2;
-      if (dproj && sampled) {
+      if (has_proj && sampled) {
         const float du = gp0, dv = gp1;
         const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
         const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
@@ -312,17 +336,19 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restric
 
 int skin_bwd_nblk(int V) { return (V + SKB_T - 1) / SKB_T; }
 
-int launch_skin_bwd_partials(const float *dverts, const float *dproj, const float *v_posed,
+int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
                              int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st) {
   const int VP = (V + vs - 1) / vs;
   const dim3 grid(skin_bwd_nblk(V), (B + SKB_MB - 1) / SKB_MB);
   if (lbs_top4)
     hipLaunchKernelGGL(skin_bwd_kernel<true>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
-                       A, cam, x_stride, B, V, vs, VP, dv_posed, part);
+                       A, cam, x_stride, B, V, vs, VP, dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot),
+                       sg.nsplit);
   else
     hipLaunchKernelGGL(skin_bwd_kernel<false>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
-                       A, cam, x_stride, B, V, vs, VP, dv_posed, part);
+                       A, cam, x_stride, B, V, vs, VP, dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot),
+                       sg.nsplit);
   SMPLR_LAUNCH_CHECK("skin_bwd_kernel");
   return 0;
 }
@@ -373,8 +399,9 @@ int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed
   SMPLR_REQUIRE(dverts || dproj, "smplr_skin_bwd: need dverts and/or dproj");
   SMPLR_REQUIRE(!dproj || (cam && x_stride >= 4), "smplr_skin_bwd: dproj given without camera rows");
   const int nblk = skin_bwd_nblk(V);
-  int rc = launch_skin_bwd_partials(dverts, dproj, v_posed, lbs_weights, lbs_top4, A, cam, x_stride, B, V,
-                                    vertex_sampling, dv_posed, reinterpret_cast<float *>(workspace), as_stream(stream));
+  int rc = launch_skin_bwd_partials(dverts, dproj, SegGrad{nullptr, nullptr, 0}, v_posed, lbs_weights, lbs_top4, A, cam,
+                                    x_stride, B, V, vertex_sampling, dv_posed, reinterpret_cast<float *>(workspace),
+                                    as_stream(stream));
   if (rc) return rc;
   hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(B), dim3(320), 0, as_stream(stream),
                      reinterpret_cast<const float *>(workspace), nblk, dA, dcam);

@@ -214,8 +214,10 @@ def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_ve
 
 
 def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJt, vertex_sampling=1,
-              out=None):
-    """dverts and/or dproj (+ optional dJ_transformed) -> dx (B, x_stride)."""
+              out=None, seg_grad=None):
+    """dverts and/or dproj (+ optional dJ_transformed) -> dx (B, x_stride).
+    seg_grad = (part, vslot, nsplit): the segmentation gradient as _seg_bwd(..., merge=False) leaves it,
+    gathered by vertex inside the skinning backward and added to dproj."""
     lib = _lib.load()
     B = x.shape[0]
     vs = int(vertex_sampling)
@@ -223,7 +225,9 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
     if x.shape[1] > num_cam + 82:
         dx.zero_()
     ws = _workspace(lib.smplr_smpl_bwd_workspace(B, c.V), x)
-    check(lib.smplr_smpl_bwd(ptr(dverts), ptr(dproj), ptr(dJt), ptr(x), x.shape[1], num_cam, B, c.V, vs,
+    sp, sv, sn = seg_grad if seg_grad is not None else (None, None, 0)
+    check(lib.smplr_smpl_bwd(ptr(dverts), ptr(dproj), ptr(sp), ptr(sv), int(sn), ptr(dJt), ptr(x), x.shape[1],
+                             num_cam, B, c.V, vs,
                              ptr(c.blend_t), ptr(c.blend3_bwd), ptr(c.lbs_weights), ptr(c.lbs_top4), ptr(c.J_dirs), ptr(c.parents),
                              ptr(Rs), ptr(J),
                              ptr(A), ptr(v_posed), ptr(dx), ptr(ws), stream()), "smplr_smpl_bwd")
@@ -243,7 +247,8 @@ def visibility(proj, grid_wh=64, ref_compat=True, out=None):
     return mask
 
 
-def _seg_fwd(proj, mask, W, pt: PartTable, out=None):
+def _seg_fwd(proj, mask, W, pt: PartTable, out=None, vslot=None):
+    """vslot (B,VP) int16, optional output: each vertex' record slot, for the gather form of the backward."""
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
     if VP != pt.VP:
@@ -256,11 +261,11 @@ def _seg_fwd(proj, mask, W, pt: PartTable, out=None):
         arg = _empty((B, W, W, 32), proj, torch.int16)
         rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
     check(lib.smplr_seg_fwd(ptr(proj), ptr(mask), B, VP, W, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
-                            pt.K, ptr(ws), ptr(seg), ptr(arg), ptr(rec), stream()), "smplr_seg_fwd")
+                            pt.K, ptr(ws), ptr(seg), ptr(arg), ptr(rec), ptr(vslot), stream()), "smplr_seg_fwd")
     return seg, arg, rec
 
 
-def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None):
+def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None, vslot=None):
     """compute_mask + projects_to_seg in one call (smplr_vis_seg_fwd): -> mask, seg, arg, rec."""
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
@@ -276,18 +281,20 @@ def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None):
         rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
     check(lib.smplr_vis_seg_fwd(ptr(proj), B, VP, W, int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos),
                                 ptr(pt.part_off), pt.P, pt.K, ptr(ws), ptr(mask), ptr(seg), ptr(arg), ptr(rec),
-                                stream()), "smplr_vis_seg_fwd")
+                                ptr(vslot), stream()), "smplr_vis_seg_fwd")
     return mask, seg, arg, rec
 
 
-def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable):
+def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True):
+    """merge=True -> dproj (B,VP,3).  merge=False -> (part, nsplit): the per-row-block slot sums, to be handed
+    to _smpl_bwd(seg_grad=(part, vslot, nsplit)) which gathers them by vertex (no merge launch, no dproj)."""
     lib = _lib.load()
     B = arg.shape[0]
-    dproj = _empty((B, VP, 3), dseg)
     ws = _workspace(lib.smplr_seg_bwd_workspace(B, W), dseg)
+    dproj = _empty((B, VP, 3), dseg) if merge else None
     check(lib.smplr_seg_bwd(ptr(dseg), ptr(arg), ptr(rec), B, VP, W, pt.P, pt.K, ptr(dproj), ptr(ws),
                             stream()), "smplr_seg_bwd")
-    return dproj
+    return dproj if merge else (ws, int(lib.smplr_seg_bwd_nsplit(W)))
 
 
 def argmin_vertices(arg, rec):
@@ -579,6 +586,7 @@ class DecoderFn(torch.autograd.Function):
         mask = _empty((B, VP), x)
         seg, arg = _empty((B, W, W, pt.P + 1), x), _empty((B, W, W, 32), x, torch.int16)
         rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), x)
+        vslot = _empty((B, VP), x, torch.int16)
         if with_silh:
             silh, sarg = _empty((B, W, W, 2), x), _empty((B, W, W), x, torch.int32)
         else:
@@ -591,7 +599,7 @@ class DecoderFn(torch.autograd.Function):
             _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
                       out=(verts[lo:hi], proj[lo:hi]))
             _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,
-                         out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]))
+                         out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
             if with_silh:
                 _silh_fwd(proj[lo:hi], W, out=(silh[lo:hi], sarg[lo:hi]))
 
@@ -600,13 +608,13 @@ class DecoderFn(torch.autograd.Function):
             _run_chunks(bounds, x.device, run)
         ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, with_silh
         ctx.bounds = bounds
-        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg)
+        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot)
         ctx.mark_non_differentiable(mask)
         return verts, proj, mask, seg, silh, Jt
 
     @staticmethod
     def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
-        x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg = ctx.saved_tensors
+        x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot = ctx.saved_tensors
         dseg = require_cuda(dseg, "dseg") if dseg is not None else None
         dsilh = require_cuda(dsilh, "dsilh") if (ctx.with_silh and dsilh is not None) else None
         dproj_in = require_cuda(dproj_in, "dproj") if dproj_in is not None else None
@@ -616,19 +624,21 @@ class DecoderFn(torch.autograd.Function):
         dx = _empty(tuple(x.shape), x)
 
         def run(lo, hi):
-            dproj = None
+            dproj, seg_grad = None, None
             if dseg is not None:
-                dproj = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt)
+                # the slot sums stay in the workspace; the skinning backward gathers them by vertex
+                part, nsplit = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt, merge=False)
+                seg_grad = (part, vslot[lo:hi], nsplit)
             if dsilh is not None:
                 d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.W)
                 dproj = d2 if dproj is None else dproj + d2
             if dproj_in is not None:
                 dproj = dproj_in[lo:hi] if dproj is None else dproj + dproj_in[lo:hi]
             dv = dverts[lo:hi] if dverts is not None else None
-            if dv is None and dproj is None:
+            if dv is None and dproj is None and seg_grad is None:
                 dv = torch.zeros_like(v_posed[lo:hi])
             _smpl_bwd(x[lo:hi], ctx.num_cam, ctx.consts, Rs[lo:hi], J[lo:hi], A[lo:hi], v_posed[lo:hi], dv,
-                      dproj, dJt[lo:hi] if dJt is not None else None, ctx.vs, out=dx[lo:hi])
+                      dproj, dJt[lo:hi] if dJt is not None else None, ctx.vs, out=dx[lo:hi], seg_grad=seg_grad)
 
         if x.shape[0] > 0:
             _run_chunks(ctx.bounds, x.device, run)

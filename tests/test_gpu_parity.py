@@ -673,6 +673,61 @@ def test_seg_backward_many_records_windows(layer, part_tables):
     grad_close(d1.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(seg, windows)")
 
 
+@pytest.mark.parametrize("vs,W,all_visible", [(1, 48, False), (2, 50, False), (1, 48, True)])
+def test_seg_gradient_gathered_by_vertex_equals_merged(layer, smpl_model, vs, W, all_visible):
+    """The decoder's backward leaves the segmentation gradient as per-row-block slot sums and lets the skinning
+    backward gather them by vertex (vslot).  Fed the SAME slot sums, that must equal, bit for bit, merging them
+    into dproj first (here: the merge kernel's arithmetic restated in torch, slot by slot in block order) - also
+    when a mesh needs several slot windows (all_visible: > 4096 records) and on top of an explicit dproj."""
+    from ilps_amd import ops
+    d = dev()
+    c = ops.SMPLConstants.from_model(smpl_model, d)
+    pt = ops.get_part_table(vs, d, c.V)
+    B = 3
+    x = t(make_x(B, W, seed=500 + vs))
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
+    vp = ops._blend_fwd(coef, c, B)
+    verts, proj = ops._skin_fwd(vp, A, c, cam=x, vertex_sampling=vs)
+    VP = proj.shape[1]
+    mask = torch.ones(B, VP, device=d) if all_visible else ops.visibility(proj)
+    vslot = torch.full((B, VP), -7, dtype=torch.int16, device=d)
+    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt, vslot=vslot)
+    # vslot is the inverse of the records' vertex column
+    pos = rec[..., 3].contiguous().view(torch.int32).long()                       # (B,S)
+    for b in range(B):
+        nb = int(rec[b, -1, 0].view(torch.int32).item())
+        if all_visible:
+            assert nb > 4096
+        used = torch.arange(nb, device=d)[pos[b, :nb] >= 0]
+        assert torch.equal(vslot[b, pos[b, used]].long(), used)
+        has = torch.zeros(VP, dtype=torch.bool, device=d)
+        has[pos[b, used]] = True
+        assert torch.all(vslot[b][~has] == -1) and torch.all(vslot[b][has] >= 0)
+    g = t(np.random.default_rng(9).normal(0, 1, (B, W, W, 32)))
+    part, nsplit = ops._seg_bwd(g, arg, rec, VP, W, pt, merge=False)
+    S = rec.shape[1]
+    P4 = part[:B * nsplit * 5 * 4096 * 2].view(B, nsplit, 5 * 4096, 2)
+    acc = torch.zeros(B, S, 2, device=d)
+    for sblk in range(nsplit):
+        acc = acc + P4[:, sblk, :S]
+    dproj = torch.zeros(B, VP, 3, device=d)
+    for b in range(B):
+        nb = int(rec[b, -1, 0].view(torch.int32).item())
+        used = torch.arange(nb, device=d)[pos[b, :nb] >= 0]
+        dproj[b, pos[b, used], :2] = acc[b, used]
+    extra = t(np.random.default_rng(10).normal(0, 1, (B, VP, 3)))
+    dv = t(np.random.default_rng(11).normal(0, 1, (B, c.V, 3)))
+    for explicit in (None, extra):
+        merged = dproj if explicit is None else explicit + dproj
+        want = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, dv, merged, None, vs)
+        got = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, dv, explicit, None, vs, seg_grad=(part, vslot, nsplit))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    # and the merge kernel itself agrees with its restatement
+    d1 = ops._seg_bwd(g, arg, rec, VP, W, pt)
+    assert torch.allclose(d1, dproj, rtol=1e-4, atol=1e-6)
+
+
 # ----------------------------------------------------------------------------------- BASELINE-size batches
 def test_full_size_batch_is_row_independent(smpl_model):
     """B = 160 (BASELINE configs[2] is 128; 160 = one full 128-mesh group + a ragged one, 5 mesh tiles
