@@ -64,26 +64,53 @@ def event_time_ms(fn, reps, stream):
 
 
 def stage_breakdown(x, consts, pt, W, reps=20):
-    """Per-C-ABI-call mean times (us) on the current stream; same kernels as the timed step."""
+    """Per-C-ABI-call mean times (us) on the current stream; same kernels, same call sequence as the timed step."""
     st = torch.cuda.current_stream()
     B = x.shape[0]
+    VP = consts.V
     res = {}
     coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts)
     res["pose_fwd"] = event_time_ms(lambda: ops._pose_fwd(x, 4, consts), reps, st)
-    v_posed = ops._blend_fwd(coef, consts, x.shape[0])
-    res["blend_fwd"] = event_time_ms(lambda: ops._blend_fwd(coef, consts, x.shape[0]), reps, st)
+    v_posed = ops._blend_fwd(coef, consts, B)
+    res["blend_fwd"] = event_time_ms(lambda: ops._blend_fwd(coef, consts, B), reps, st)
     verts, proj = ops._skin_fwd(v_posed, A, consts, cam=x)
     res["skin_fwd"] = event_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
-    mask = ops.visibility(proj)
-    res["visibility"] = event_time_ms(lambda: ops.visibility(proj), reps, st)
-    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt)
-    res["seg_fwd"] = event_time_ms(lambda: ops._seg_fwd(proj, mask, W, pt), reps, st)
+    vslot = torch.empty(B, VP, dtype=torch.int16, device=x.device)
+    mask, seg, arg, rec = ops._vis_seg_fwd(proj, W, pt, vslot=vslot)
+    res["vis_seg_fwd"] = event_time_ms(lambda: ops._vis_seg_fwd(proj, W, pt, vslot=vslot), reps, st)
     dseg = torch.randn_like(seg)
-    dproj = ops._seg_bwd(dseg, arg, rec, proj.shape[1], W, pt)
-    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, arg, rec, proj.shape[1], W, pt), reps, st)
+    part, nsplit = ops._seg_bwd(dseg, arg, rec, VP, W, pt, merge=False)
+    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, arg, rec, VP, W, pt, merge=False), reps, st)
     res["smpl_bwd(skin+blend+pose)"] = event_time_ms(
-        lambda: ops._smpl_bwd(x, 4, consts, Rs, J, A, v_posed, None, dproj, None), reps, st)
+        lambda: ops._smpl_bwd(x, 4, consts, Rs, J, A, v_posed, None, None, None, seg_grad=(part, vslot, nsplit)),
+        reps, st)
     return {k: round(v * 1e3, 2) for k, v in res.items()}
+
+
+def stage_rooflines(stages, B, W, V, gemm):
+    """Each stage against the roof that bounds it, from ALGORITHMIC work per mesh
+    and the live HIP-event time of the call (includes ~2-3 us of launch per kernel; rocprofv3 kernel times are in
+    profiles/).  Bytes are compulsory traffic: inputs read once + outputs written once + constants once per batch."""
+    npx = W * W
+    n3 = 3 * V
+    const_fwd = (n3 * 224 * 6) if gemm == "bf16x3" else (n3 * 220 * 4)     # packed bf16x3 constant: 6 B per entry
+    rows = [
+        # name, bound, work per launch, unit scale
+        ("blend_fwd", "mfma", 2.0 * 220 * n3 * B, None),
+        ("blend_fwd", "hbm", const_fwd + n3 * 4 * B, None),
+        ("skin_fwd", "hbm", (3 * n3 * 4 + 288 * 4) * B + V * 32, None),            # v_posed in, verts + proj out
+        ("seg_bwd", "hbm", npx * (32 * 4 + 32 * 2) * B, None),                     # dseg + arg in (slot sums are small)
+    ]
+    out = []
+    for name, bound, work, _ in rows:
+        t = stages[name] * 1e-6
+        if bound == "mfma":
+            ach, peak, unit = work / t / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = work / t / 1e9, HBM_PEAK_GBS, "GB/s"
+        out.append({"stage": name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                    "frac": round(ach / peak, 4), "us": stages[name]})
+    return out
 
 
 def cpu_baseline(model, W, budget_s=20.0):
@@ -258,12 +285,16 @@ def main():
                                    "projects_to_seg), BASELINE configs[2]",
                        "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,
                        "params_per_mesh": 86, "launch": mode, "concurrent_chunks": args.streams,
+                       "blend_gemm": ("bf16x3: fp32 operands as 3 bf16 terms (24 significant bits), 6 partial "
+                                      "products, fp32 accumulation" if ops.blend_gemm_mode() == "bf16x3"
+                                      else "fp32 MFMA"),
                        "sharding": "by mesh, no collective"},
         }
         if not args.no_breakdown:
             stages = stage_breakdown(x, consts, pt, W)
             line["stages_us"] = stages
-            t_seg = stages["seg_fwd"] * 1e-6
+            line["stage_rooflines"] = stage_rooflines(stages, B, W, consts.V, ops.blend_gemm_mode())
+            t_seg = stages["vis_seg_fwd"] * 1e-6
             flop = SEG_FWD_FLOP_PER_MESH * B if W == 48 else (W * W * 6879 * 7 + W * W * 62) * B
             ach = flop / t_seg / 1e12
             traffic = None
@@ -279,7 +310,7 @@ def main():
             nvis = float((ops.visibility(pj) == 1.0).sum().item()) / B
             executed = (W * W * nvis * 10.0 * B) / t_seg / 1e12
             line["roofline"] = {
-                "kernel": "seg_bin_kernel + raster_fwd_kernel (smplr_seg_fwd)", "bound": "mfma",
+                "kernel": "seg_bin_kernel + raster_fwd_kernel (smplr_vis_seg_fwd)", "bound": "mfma",
                 "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                 "executed_tflops": round(executed, 3), "executed_frac": round(executed / FP32_PEAK_TFLOPS, 4),
@@ -288,7 +319,7 @@ def main():
                         "equals the fp32 MFMA peak (157.3 TF). achieved = ALGORITHMIC FLOPs (SURVEY 8(d): 111 "
                         "MFLOP/mesh x B) / launch time; it can exceed the pipe's real utilisation because pairs "
                         "whose fp32 score is provably 0 are never evaluated: executed_* counts only evaluated pairs",
-                "launch_us": stages["seg_fwd"],
+                "launch_us": stages["vis_seg_fwd"],
             }
         if not args.no_breakdown:
             # BASELINE configs[1]: batch_smpl fwd+bwd only, B=256, eager, HIP events

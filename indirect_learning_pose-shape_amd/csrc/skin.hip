@@ -176,13 +176,14 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     const int sl = max(slot, 0), win = sl / SB_SLOTS;
     const float *sp = seg_part + ((size_t)n * seg_nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (sl - win * SB_SLOTS) * 2;
     float sx = 0.0f, sy = 0.0f;
-    for (int s0 = 0; s0 < seg_nsplit; s0 += 8) {
-      float2 t[8];
+    constexpr int GC = 6;                     // row blocks requested together (W = 48: all six)
+    for (int s0 = 0; s0 < seg_nsplit; s0 += GC) {
+      float2 t[GC];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < GC; ++u)
         t[u] = *reinterpret_cast<const float2 *>(sp + (size_t)min(s0 + u, seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GC; ++u) {
         sx += (s0 + u < seg_nsplit) ? t[u].x : 0.0f;
         sy += (s0 + u < seg_nsplit) ? t[u].y : 0.0f;
       }
