@@ -63,6 +63,34 @@ def event_time_ms(fn, reps, stream):
     return e0.elapsed_time(e1) / reps
 
 
+def graph_time_ms(fn, reps, stream):
+    """Mean duration of fn() in ms with `reps` back-to-back calls replayed from one HIP graph (no host launch time
+    in the figure; HIP events on the replay stream).  Falls back to event_time_ms if capture is refused."""
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(stream)
+        with torch.cuda.stream(s):
+            fn()
+        stream.wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(3):
+            g.replay()
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / (3 * reps)
+    except Exception:
+        torch.cuda.synchronize()
+        return event_time_ms(fn, reps, stream)
+
+
 def stage_breakdown(x, consts, pt, W, reps=20):
     """Per-C-ABI-call mean times (us) on the current stream; same kernels, same call sequence as the timed step."""
     st = torch.cuda.current_stream()
@@ -70,18 +98,18 @@ def stage_breakdown(x, consts, pt, W, reps=20):
     VP = consts.V
     res = {}
     coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts)
-    res["pose_fwd"] = event_time_ms(lambda: ops._pose_fwd(x, 4, consts), reps, st)
+    res["pose_fwd"] = graph_time_ms(lambda: ops._pose_fwd(x, 4, consts), reps, st)
     v_posed = ops._blend_fwd(coef, consts, B)
-    res["blend_fwd"] = event_time_ms(lambda: ops._blend_fwd(coef, consts, B), reps, st)
+    res["blend_fwd"] = graph_time_ms(lambda: ops._blend_fwd(coef, consts, B), reps, st)
     verts, proj = ops._skin_fwd(v_posed, A, consts, cam=x)
-    res["skin_fwd"] = event_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
+    res["skin_fwd"] = graph_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
     vslot = torch.empty(B, VP, dtype=torch.int16, device=x.device)
     mask, seg, arg, rec = ops._vis_seg_fwd(proj, W, pt, vslot=vslot)
-    res["vis_seg_fwd"] = event_time_ms(lambda: ops._vis_seg_fwd(proj, W, pt, vslot=vslot), reps, st)
+    res["vis_seg_fwd"] = graph_time_ms(lambda: ops._vis_seg_fwd(proj, W, pt, vslot=vslot), reps, st)
     dseg = torch.randn_like(seg)
     part, nsplit = ops._seg_bwd(dseg, arg, rec, VP, W, pt, merge=False)
-    res["seg_bwd"] = event_time_ms(lambda: ops._seg_bwd(dseg, arg, rec, VP, W, pt, merge=False), reps, st)
-    res["smpl_bwd(skin+blend+pose)"] = event_time_ms(
+    res["seg_bwd"] = graph_time_ms(lambda: ops._seg_bwd(dseg, arg, rec, VP, W, pt, merge=False), reps, st)
+    res["smpl_bwd(skin+blend+pose)"] = graph_time_ms(
         lambda: ops._smpl_bwd(x, 4, consts, Rs, J, A, v_posed, None, None, None, seg_grad=(part, vslot, nsplit)),
         reps, st)
     return {k: round(v * 1e3, 2) for k, v in res.items()}
@@ -89,8 +117,8 @@ def stage_breakdown(x, consts, pt, W, reps=20):
 
 def stage_rooflines(stages, B, W, V, gemm):
     """Each stage against the roof that bounds it, from ALGORITHMIC work per mesh
-    and the live HIP-event time of the call (includes ~2-3 us of launch per kernel; rocprofv3 kernel times are in
-    profiles/).  Bytes are compulsory traffic: inputs read once + outputs written once + constants once per batch."""
+    and the live time of the call replayed from a HIP graph (HIP events; includes the ~2 us kernel-to-kernel gap;
+    rocprofv3 kernel times are in profiles/).  Bytes are compulsory traffic: inputs read once + outputs written once + constants once per batch."""
     npx = W * W
     n3 = 3 * V
     const_fwd = (n3 * 224 * 6) if gemm == "bf16x3" else (n3 * 220 * 4)     # packed bf16x3 constant: 6 B per entry

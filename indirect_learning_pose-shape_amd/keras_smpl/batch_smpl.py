@@ -1,7 +1,7 @@
 """SMPLLayer: drop-in for `keras_smpl/batch_smpl.py:23-153` of the reference, on HIP kernels.
 
-forward = smplr_pose_fwd -> smplr_blend_fwd (fp32 MFMA GEMM) -> smplr_skin_fwd; the backward is
-hand-written (smplr_skin_bwd -> smplr_blend_bwd -> smplr_pose_bwd).  SMPL constants are
+forward = smplr_pose_fwd -> smplr_blend3_fwd (bf16x3 MFMA GEMM; the fp32-MFMA smplr_blend_fwd with
+SMPLR_BLEND_GEMM=f32) -> smplr_skin_fwd; the backward is hand-written (smplr_smpl_bwd = skin, blend, pose).  SMPL constants are
 non-trainable buffers, exactly as in the reference (`batch_smpl.py:92-94`).
 """
 from __future__ import annotations
