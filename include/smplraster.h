@@ -243,6 +243,24 @@ size_t smplr_prelu_bwd_workspace(long long N, int C, int HW);
 int smplr_prelu_bwd(const float *x, const float *w, const float *gy, long long N, int C, int HW,
                     float *gx, float *gw, void *workspace, void *stream);
 
+/* ---- BatchNormalization (+ PReLU) of the ENet encoder, training mode:
+ *      encoders/encoder_enet_simple.py:19-21,35-37,48-50,56-58,76 ---------- */
+/* x (N, C, HW) NCHW fp32.  Forward: batch statistics per channel over (N, HW) (biased variance), running_mean /
+ * running_var updated in place as torch.nn.BatchNorm2d does (momentum = weight of the new value; unbiased
+ * variance; either may be NULL), z = prelu(gamma (x - mean) rstd + beta, slope); slope (C) = NULL: no
+ * activation.  save_mean / save_rstd (C) are what the backward needs besides x.
+ * Backward: dz -> dx, dgamma, dbeta (C) and dslope (C, iff slope); y and x_hat are recomputed from x.
+ * workspace: smplr_bn_workspace(N,C,HW) bytes (per-chunk partial sums, added in a fixed order).          */
+size_t smplr_bn_workspace(long long N, int C, int HW);
+int smplr_bn_fwd(const float *x, const float *gamma, const float *beta, const float *slope,
+                 long long N, int C, int HW, float eps, float momentum,
+                 float *running_mean, float *running_var, float *z, float *save_mean, float *save_rstd,
+                 void *workspace, void *stream);
+int smplr_bn_bwd(const float *x, const float *gamma, const float *beta, const float *slope,
+                 const float *save_mean, const float *save_rstd, const float *dz,
+                 long long N, int C, int HW, float *dx, float *dgamma, float *dbeta, float *dslope,
+                 void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,9 @@ SIGNATURES = {
     "smplr_prelu_fwd": (c_int, [P, P, c_longlong, I, I, P, P]),
     "smplr_prelu_bwd_workspace": (c_size_t, [c_longlong, I, I]),
     "smplr_prelu_bwd": (c_int, [P, P, P, c_longlong, I, I, P, P, P, P]),
+    "smplr_bn_workspace": (c_size_t, [c_longlong, I, I]),
+    "smplr_bn_fwd": (c_int, [P, P, P, P, c_longlong, I, I, c_float, c_float, P, P, P, P, P, P, P]),
+    "smplr_bn_bwd": (c_int, [P, P, P, P, P, P, P, c_longlong, I, I, P, P, P, P, P, P]),
 }
 
 _lib = None

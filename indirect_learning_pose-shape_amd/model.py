@@ -61,7 +61,12 @@ class _Bottleneck(nn.Module):
         self.act = PReLU(cout)
 
     def forward(self, x):
-        y = self.expand(self.conv(self.reduce(x)))
+        from .ops import batch_norm_act                   # BatchNormalization (+ PReLU) as one HIP op when training
+        y = batch_norm_act(self.reduce[0](x), self.reduce[1], self.reduce[2])
+        for m in list(self.conv)[:-2]:
+            y = m(y)
+        y = batch_norm_act(y, self.conv[-2], self.conv[-1])
+        y = self.expand[2](batch_norm_act(self.expand[0](y), self.expand[1]))
         other = x
         if self.downsample:
             other = F.max_pool2d(other, 2)
@@ -88,8 +93,9 @@ class ENetEncoder(nn.Module):
         self.blocks = nn.Sequential(*blocks)
 
     def forward(self, x):
+        from .ops import batch_norm_act
         x = torch.cat([self.init_conv(x), F.max_pool2d(x, 2)], dim=1)
-        return self.blocks(self.init_act(self.init_bn(x)))
+        return self.blocks(batch_norm_act(x, self.init_bn, self.init_act))
 
 
 class _ENetBackbone(nn.Module):

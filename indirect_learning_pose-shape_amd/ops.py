@@ -520,6 +520,62 @@ class PReLUFn(torch.autograd.Function):
         return gx, gw
 
 
+class BatchNormActFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ per-channel PReLU) on NCHW fp32: smplr_bn_fwd / smplr_bn_bwd (the ENet
+    encoder's `BatchNormalization` + `PReLU(shared_axes=[1, 2])` pairs, encoders/encoder_enet_simple.py:19-21).
+    running_mean / running_var are updated in place like torch.nn.BatchNorm2d; slope = None: no activation."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, running_mean, running_var, eps, momentum):
+        lib = _lib.load()
+        x = require_cuda(x, "x")
+        gamma, beta = require_cuda(gamma, "gamma"), require_cuda(beta, "beta")
+        slope = require_cuda(slope, "slope") if slope is not None else None
+        N, C = x.shape[0], x.shape[1]
+        if gamma.numel() != C or beta.numel() != C or (slope is not None and slope.numel() != C):
+            raise RuntimeError("batch norm parameters need %d entries" % C)
+        HW = x.numel() // (N * C) if N * C else 1
+        z = torch.empty_like(x)
+        mean, rstd = _empty((C,), x), _empty((C,), x)
+        ws = _workspace(lib.smplr_bn_workspace(N, C, HW), x)
+        check(lib.smplr_bn_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(slope), N, C, HW, float(eps), float(momentum),
+                               ptr(running_mean), ptr(running_var), ptr(z), ptr(mean), ptr(rstd), ptr(ws), stream()),
+              "smplr_bn_fwd")
+        ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
+        ctx.dims = (N, C, HW)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        x, gamma, beta, slope, mean, rstd = ctx.saved_tensors
+        N, C, HW = ctx.dims
+        dz = require_cuda(dz, "dz")
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ds = torch.empty_like(slope) if slope is not None else None
+        ws = _workspace(lib.smplr_bn_workspace(N, C, HW), x)
+        check(lib.smplr_bn_bwd(ptr(x), ptr(gamma), ptr(beta), ptr(slope), ptr(mean), ptr(rstd), ptr(dz), N, C, HW,
+                               ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(ws), stream()), "smplr_bn_bwd")
+        return dx, dg, db, ds, None, None, None, None
+
+
+def batch_norm_act(x, bn, act=None):
+    """`act(bn(x))` for a torch.nn.BatchNorm2d and an optional per-channel nn.PReLU.  Training mode on a HIP
+    device with planes of >= 256 elements runs the fused HIP kernels; everything else (eval mode, CPU, tiny
+    planes, other dtypes) takes the stock modules.  Parameters, buffers and state dict are the modules' own."""
+    fused = (bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine
+             and bn.track_running_stats and bn.momentum is not None and x.shape[2] * x.shape[3] >= 256
+             and (act is None or act.weight.numel() == x.shape[1]) and x.shape[0] > 0)
+    if not fused:
+        y = bn(x)
+        return act(y) if act is not None else y
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormActFn.apply(x.contiguous(), bn.weight, bn.bias, act.weight if act is not None else None,
+                                bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+
+
 _side_streams = {}
 
 

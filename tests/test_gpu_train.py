@@ -91,3 +91,57 @@ def test_prelu_kernels_match_torch(shape):
     assert torch.allclose(y.detach().cpu().double(), y64.detach(), rtol=1e-6, atol=1e-7)
     assert torch.allclose(xd.grad.cpu().double(), x64.grad, rtol=1e-6, atol=1e-7)
     assert torch.allclose(wd.grad.cpu().double(), w64.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape,with_act", [((6, 16, 128, 128), True), ((5, 3, 33, 31), True), ((4, 64, 32, 32), False),
+                                            ((2, 5, 16, 16), True), ((3, 7, 70, 70), False)])
+def test_batch_norm_act_kernels_match_torch(shape, with_act):
+    """smplr_bn_fwd/bwd (training-mode BatchNorm2d + optional PReLU in one op) against torch's own modules in
+    float64 on the CPU: output, input gradient, gamma / beta / slope gradients, running statistics and the batch
+    counter; twice in a row on the same input must be bit-identical (fixed summation order)."""
+    from ilps_amd import ops
+    from ilps_amd.model import PReLU
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    x = torch.randn(*shape, generator=g) * 2.0 + 0.5
+    gy = torch.randn(*shape, generator=g)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    act = PReLU(C) if with_act else None
+    if act is not None:
+        with torch.no_grad():
+            act.weight.copy_(torch.rand(C, generator=g) * 0.5 - 0.1)
+    import copy
+    bn64, act64 = copy.deepcopy(bn).double().train(), (copy.deepcopy(act).double() if act is not None else None)
+    bnd, actd = copy.deepcopy(bn).to(dev).train(), (copy.deepcopy(act).to(dev) if act is not None else None)
+    xd = x.to(dev).requires_grad_(True)
+    z = ops.batch_norm_act(xd, bnd, actd)
+    assert z.grad_fn is not None and "BatchNormActFn" in type(z.grad_fn).__name__      # the HIP op ran
+    z.backward(gy.to(dev))
+    x64 = x.double().requires_grad_(True)
+    y64 = bn64(x64)
+    z64 = torch.nn.functional.prelu(y64, act64.weight) if act64 is not None else y64
+    z64.backward(gy.double())
+    close = lambda a, b, tol: torch.allclose(a.detach().cpu().double(), b.detach(), rtol=tol, atol=tol)
+    assert close(z, z64, 2e-5)
+    assert close(xd.grad, x64.grad, 2e-4)
+    assert close(bnd.weight.grad, bn64.weight.grad, 2e-4) and close(bnd.bias.grad, bn64.bias.grad, 2e-4)
+    if act is not None:
+        assert close(actd.weight.grad, act64.weight.grad, 2e-4)
+    assert close(bnd.running_mean, bn64.running_mean, 1e-5) and close(bnd.running_var, bn64.running_var, 1e-5)
+    assert int(bnd.num_batches_tracked) == int(bn64.num_batches_tracked) == 1
+    # repeatable bit for bit
+    bn2 = copy.deepcopy(bn).to(dev).train()
+    x2 = x.to(dev).requires_grad_(True)
+    z2 = ops.batch_norm_act(x2, bn2, copy.deepcopy(act).to(dev) if act is not None else None)
+    z2.backward(gy.to(dev))
+    assert torch.equal(z2, z) and torch.equal(x2.grad, xd.grad)
+    # eval mode and tiny planes take the stock modules
+    bnd.eval()
+    ze = ops.batch_norm_act(x.to(dev), bnd, actd)
+    assert "BatchNormActFn" not in type(ze.grad_fn).__name__ if ze.grad_fn is not None else True
