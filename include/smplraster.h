@@ -261,6 +261,20 @@ int smplr_bn_bwd(const float *x, const float *gamma, const float *beta, const fl
                  long long N, int C, int HW, float *dx, float *dgamma, float *dbeta, float *dslope,
                  void *workspace, void *stream);
 
+/* The tail of an ENet bottleneck in one pass (encoder_enet_simple.py:56-79: BatchNormalization ->
+ * SpatialDropout2D -> Add -> PReLU):  out = prelu(plane_scale[n,c] * bn(x) + other, slope).
+ * plane_scale (N*C) = the dropout factor of each (image, channel) plane (0 or 1/(1-p)); NULL = 1.
+ * other (N,C,HW) = the bottleneck's other branch.  Backward: dout -> dx, dother, dgamma, dbeta, dslope.   */
+int smplr_bn_res_fwd(const float *x, const float *gamma, const float *beta, const float *plane_scale,
+                     const float *other, const float *slope, long long N, int C, int HW, float eps,
+                     float momentum, float *running_mean, float *running_var, float *out,
+                     float *save_mean, float *save_rstd, void *workspace, void *stream);
+int smplr_bn_res_bwd(const float *x, const float *gamma, const float *beta, const float *plane_scale,
+                     const float *other, const float *slope, const float *save_mean,
+                     const float *save_rstd, const float *dout, long long N, int C, int HW,
+                     float *dx, float *dother, float *dgamma, float *dbeta, float *dslope,
+                     void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,8 @@ SIGNATURES = {
     "smplr_bn_workspace": (c_size_t, [c_longlong, I, I]),
     "smplr_bn_fwd": (c_int, [P, P, P, P, c_longlong, I, I, c_float, c_float, P, P, P, P, P, P, P]),
     "smplr_bn_bwd": (c_int, [P, P, P, P, P, P, P, c_longlong, I, I, P, P, P, P, P, P]),
+    "smplr_bn_res_fwd": (c_int, [P, P, P, P, P, P, c_longlong, I, I, c_float, c_float, P, P, P, P, P, P, P]),
+    "smplr_bn_res_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_longlong, I, I, P, P, P, P, P, P, P]),
 }
 
 _lib = None

@@ -61,18 +61,18 @@ class _Bottleneck(nn.Module):
         self.act = PReLU(cout)
 
     def forward(self, x):
-        from .ops import batch_norm_act                   # BatchNormalization (+ PReLU) as one HIP op when training
+        # BatchNormalization (+ PReLU), and the BN -> dropout -> add -> PReLU tail, as single HIP ops when training
+        from .ops import batch_norm_act, batch_norm_residual_act
         y = batch_norm_act(self.reduce[0](x), self.reduce[1], self.reduce[2])
         for m in list(self.conv)[:-2]:
             y = m(y)
         y = batch_norm_act(y, self.conv[-2], self.conv[-1])
-        y = self.expand[2](batch_norm_act(self.expand[0](y), self.expand[1]))
         other = x
         if self.downsample:
             other = F.max_pool2d(other, 2)
             if self.pad_ch > 0:                       # zero-pad the feature maps (:66-73)
                 other = F.pad(other, (0, 0, 0, 0, 0, self.pad_ch))
-        return self.act(y + other)
+        return batch_norm_residual_act(self.expand[0](y), self.expand[1], self.expand[2], other, self.act)
 
 
 class ENetEncoder(nn.Module):

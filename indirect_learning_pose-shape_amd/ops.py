@@ -560,6 +560,68 @@ class BatchNormActFn(torch.autograd.Function):
         return dx, dg, db, ds, None, None, None, None
 
 
+class BatchNormResActFn(torch.autograd.Function):
+    """out = prelu(plane_scale * bn(x) + other, slope): the tail of an ENet bottleneck (BatchNormalization ->
+    SpatialDropout2D -> Add -> PReLU, encoders/encoder_enet_simple.py:56-79) as one op (smplr_bn_res_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, other, gamma, beta, slope, plane_scale, running_mean, running_var, eps, momentum):
+        lib = _lib.load()
+        x, other = require_cuda(x, "x"), require_cuda(other, "other")
+        if other.shape != x.shape:
+            raise RuntimeError("other must have the shape of x")
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C) if N * C else 1
+        out = torch.empty_like(x)
+        mean, rstd = _empty((C,), x), _empty((C,), x)
+        ws = _workspace(lib.smplr_bn_workspace(N, C, HW), x)
+        check(lib.smplr_bn_res_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(plane_scale), ptr(other), ptr(slope), N, C, HW,
+                                   float(eps), float(momentum), ptr(running_mean), ptr(running_var), ptr(out),
+                                   ptr(mean), ptr(rstd), ptr(ws), stream()), "smplr_bn_res_fwd")
+        ctx.save_for_backward(x, other, gamma, beta, slope, plane_scale, mean, rstd)
+        ctx.dims = (N, C, HW)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, other, gamma, beta, slope, plane_scale, mean, rstd = ctx.saved_tensors
+        N, C, HW = ctx.dims
+        dout = require_cuda(dout, "dout")
+        dx, dother = torch.empty_like(x), torch.empty_like(x)
+        dg, db, ds = torch.empty_like(gamma), torch.empty_like(beta), torch.empty_like(slope)
+        ws = _workspace(lib.smplr_bn_workspace(N, C, HW), x)
+        check(lib.smplr_bn_res_bwd(ptr(x), ptr(gamma), ptr(beta), ptr(plane_scale), ptr(other), ptr(slope), ptr(mean),
+                                   ptr(rstd), ptr(dout), N, C, HW, ptr(dx), ptr(dother), ptr(dg), ptr(db), ptr(ds),
+                                   ptr(ws), stream()), "smplr_bn_res_bwd")
+        return dx, dother, dg, db, ds, None, None, None, None, None
+
+
+def _bn_fusable(x, bn):
+    return (bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and x.shape[2] * x.shape[3] >= 256
+            and x.shape[0] > 0)
+
+
+def batch_norm_residual_act(x, bn, dropout, other, act, plane_scale=None):
+    """`act(dropout(bn(x)) + other)` for nn.BatchNorm2d, nn.Dropout2d (or None), a tensor and a per-channel
+    nn.PReLU: one HIP op when training on a HIP device, the stock modules otherwise.  plane_scale (N, C): the
+    dropout factors to use instead of drawing them (tests)."""
+    if not (_bn_fusable(x, bn) and act.weight.numel() == x.shape[1] and other.shape == x.shape):
+        y = bn(x)
+        if dropout is not None:
+            y = dropout(y)
+        return act(y + other)
+    if plane_scale is None and dropout is not None and dropout.training and dropout.p > 0:
+        keep = 1.0 - float(dropout.p)
+        plane_scale = torch.empty(x.shape[0], x.shape[1], device=x.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormResActFn.apply(x.contiguous(), other.contiguous(), bn.weight, bn.bias, act.weight,
+                                   plane_scale.contiguous() if plane_scale is not None else None,
+                                   bn.running_mean, bn.running_var, bn.eps, bn.momentum)
+
+
 def batch_norm_act(x, bn, act=None):
     """`act(bn(x))` for a torch.nn.BatchNorm2d and an optional per-channel nn.PReLU.  Training mode on a HIP
     device with planes of >= 256 elements runs the fused HIP kernels; everything else (eval mode, CPU, tiny

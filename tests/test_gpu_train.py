@@ -145,3 +145,46 @@ def test_batch_norm_act_kernels_match_torch(shape, with_act):
     bnd.eval()
     ze = ops.batch_norm_act(x.to(dev), bnd, actd)
     assert "BatchNormActFn" not in type(ze.grad_fn).__name__ if ze.grad_fn is not None else True
+
+
+@pytest.mark.parametrize("shape,with_scale", [((4, 64, 64, 64), True), ((3, 5, 33, 31), True), ((2, 16, 16, 16), False)])
+def test_batch_norm_residual_act_kernels_match_torch(shape, with_scale):
+    """smplr_bn_res_fwd/bwd - prelu(plane_scale * bn(x) + other) in one op - against the stock composition in
+    float64 on the CPU with the same dropout factors: output, both input gradients, gamma / beta / slope gradients
+    and running statistics."""
+    import copy
+    from ilps_amd import ops
+    from ilps_amd.model import PReLU
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    N, C = shape[0], shape[1]
+    x, other, gy = (torch.randn(*shape, generator=g) for _ in range(3))
+    scale = None
+    if with_scale:
+        scale = (torch.rand(N, C, generator=g) > 0.3).float() / 0.7
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.1)
+    act = PReLU(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        act.weight.copy_(torch.rand(C, generator=g) * 0.6 - 0.2)          # some slopes negative
+    bn64, act64 = copy.deepcopy(bn).double().train(), copy.deepcopy(act).double()
+    bnd, actd = copy.deepcopy(bn).to(dev).train(), copy.deepcopy(act).to(dev)
+    xd, od = x.to(dev).requires_grad_(True), other.to(dev).requires_grad_(True)
+    drop = torch.nn.Dropout2d(0.3).train()
+    out = ops.batch_norm_residual_act(xd, bnd, drop if with_scale else None, od, actd,
+                                      plane_scale=scale.to(dev) if with_scale else None)
+    assert "BatchNormResActFn" in type(out.grad_fn).__name__
+    out.backward(gy.to(dev))
+    x64, o64 = x.double().requires_grad_(True), other.double().requires_grad_(True)
+    y64 = bn64(x64)
+    if with_scale:
+        y64 = y64 * scale.double()[:, :, None, None]
+    z64 = torch.nn.functional.prelu(y64 + o64, act64.weight)
+    z64.backward(gy.double())
+    close = lambda a, b, tol: torch.allclose(a.detach().cpu().double(), b.detach(), rtol=tol, atol=tol)
+    assert close(out, z64, 2e-5)
+    assert close(xd.grad, x64.grad, 2e-4) and close(od.grad, o64.grad, 2e-5)
+    assert close(bnd.weight.grad, bn64.weight.grad, 2e-4) and close(bnd.bias.grad, bn64.bias.grad, 2e-4)
+    assert close(actd.weight.grad, act64.weight.grad, 2e-4)
+    assert close(bnd.running_mean, bn64.running_mean, 1e-5) and close(bnd.running_var, bn64.running_var, 1e-5)
