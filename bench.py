@@ -385,6 +385,36 @@ def main():
                     {"graph_meshes_per_s": round(256 / (t_g * 1e-3), 1), "graph_ms_per_step": round(t_g, 4)})
             except Exception as e:
                 line["aux"]["batch_smpl_fwd_bwd_B256"]["graph_error"] = str(e)
+            # BASELINE configs[0] shape on the GPU: predict.py's forward for ONE 256x256 image (ENet + IEF on stock
+            # torch ops, random weights; decoder on the HIP path), eager launches, HIP events
+            try:
+                from ilps_amd.decoder import SMPLDecoder
+                from ilps_amd.inference import predict_batch
+                from ilps_amd.model import SMPLRegressor
+                torch.manual_seed(0)
+                reg = SMPLRegressor(W, "enet", True).to(dev).eval()
+                dec1 = SMPLDecoder(model, img_wh=W)
+                img = torch.rand(1, 3, 256, 256, device=dev)
+                for _ in range(3):
+                    predict_batch(reg, dec1, img)
+                t_p = event_time_ms(lambda: predict_batch(reg, dec1, img), 10, torch.cuda.current_stream())
+                dec_only = lambda: ops.DecoderFn.apply(x[:1], consts, 4, W, 1, pt, 64, True, False, 1)
+                dec_only()
+                t_d = graph_time_ms(dec_only, 10, torch.cuda.current_stream())
+                line["aux"]["predict_B1"] = {"ms_per_image": round(t_p, 3), "decoder_forward_us": round(t_d * 1e3, 1),
+                                             "note": "encoder + regressor + decoder forward for one image, eager launches "
+                                                     "(host-bound); decoder_forward_us = its 5 kernels replayed from a graph"}
+                try:
+                    from ilps_amd.inference import GraphedPredictor
+                    gp = GraphedPredictor(reg, dec1, img)
+                    t_g = event_time_ms(lambda: gp(img), 20, torch.cuda.current_stream())
+                    line["aux"]["predict_B1"]["graph_ms_per_image"] = round(t_g, 3)
+                    del gp
+                except Exception as e:
+                    line["aux"]["predict_B1"]["graph_error"] = str(e)
+                del reg, dec1, img
+            except Exception as e:
+                line["aux"]["predict_B1"] = {"error": str(e)}
             # silhouette rasteriser (part of configs[4]'s second loss), same meshes
             c0s = ops._pose_fwd(x, 4, consts)
             pjs = ops._skin_fwd(ops._blend_fwd(c0s[0], consts, x.shape[0]), c0s[3], consts, cam=x)[1]

@@ -188,3 +188,24 @@ def test_batch_norm_residual_act_kernels_match_torch(shape, with_scale):
     assert close(bnd.weight.grad, bn64.weight.grad, 2e-4) and close(bnd.bias.grad, bn64.bias.grad, 2e-4)
     assert close(actd.weight.grad, act64.weight.grad, 2e-4)
     assert close(bnd.running_mean, bn64.running_mean, 1e-5) and close(bnd.running_var, bn64.running_var, 1e-5)
+
+
+def test_graphed_predictor_equals_eager(smpl_model):
+    """inference.GraphedPredictor (the predict forward replayed from one HIP graph) returns what predict_batch does."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.inference import GraphedPredictor, predict_batch
+    from ilps_amd.model import SMPLRegressor
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    reg = SMPLRegressor(48, "enet", True).to(dev)
+    dec = SMPLDecoder(smpl_model, img_wh=48)
+    a, b = torch.rand(2, 3, 256, 256, device=dev), torch.rand(2, 3, 256, 256, device=dev)
+    gp = GraphedPredictor(reg, dec, a)
+    for img in (b, a):
+        got = {k: v.clone() for k, v in gp(img).items()}
+        want = predict_batch(reg, dec, img)
+        assert torch.allclose(got["smpl"], want["smpl"], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(got["verts"], want["verts"], rtol=1e-4, atol=1e-5)
+        assert got["seg_maps"].shape == want["seg_maps"].shape == (2, 48, 48)
+    with pytest.raises(RuntimeError):
+        gp(torch.rand(1, 3, 256, 256, device=dev))
