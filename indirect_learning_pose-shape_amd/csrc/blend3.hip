@@ -16,13 +16,16 @@
 // dropped products are below 2^-24 of |a b|, i.e. below the rounding of an fp32 product itself.
 // The leading product and the five corrections go to separate accumulators that are added once
 // at the end, so small terms are not absorbed one by one into a large sum.  Six bf16 MFMAs of
-// K = 16 take 192 cycles against 512 for the eight fp32 MFMAs of K = 2 they replace; both GEMMs
-// then run at the rate the packed constant (27 MB) streams in.  Measured error against the
-// float64 oracle: see tests/test_gpu_parity.py::test_blend3_matches_fp32_path.
+// K = 16 take 192 cycles against 512 for the eight fp32 MFMAs of K = 2 they replace, which leaves
+// each GEMM with its launch, one round trip, 3.4 us of matrix work and the drain of its output.
+// Measured error against float64: tests/test_gpu_parity.py::test_blend3_matches_fp32_path and
+// ::test_blend3_wide_dynamic_range (the decoder's vertex error is unchanged at 3.3e-7).
 //
 // The constant operand is split and laid out in MFMA fragment order ONCE (smplr_blend3_pack), so
-// a wave reads each 64-lane fragment with one coalesced 1-KB global_load_dwordx4; the per-step
-// operand (coef, dv_posed) is fp32 in memory and split in registers (v_cvt_pk_bf16_f32).
+// a wave reads each 64-lane fragment with one coalesced 1-KB global_load_dwordx4.  The per-step
+// operands: the forward's coef arrives already split, as A-fragments written by pose_fwd (coef3:
+// once per mesh instead of once per column tile); the backward's dv_posed is fp32 in memory and
+// split in registers (v_cvt_pk_bf16_f32 + exact fp32 residuals).
 //   forward operand  [96-col tile][k-tile 14][t 3][split 3][lane 64][8 bf16]:
 //       element j of lane (i, h) = split_s(blend[16 kt + 8h + j][96 ct + 3i + t])
 //   backward operand [k-tile ceil(N3/16)][out tile 7][split 3][lane 64][8 bf16]:
