@@ -209,3 +209,33 @@ def test_graphed_predictor_equals_eager(smpl_model):
         assert got["seg_maps"].shape == want["seg_maps"].shape == (2, 48, 48)
     with pytest.raises(RuntimeError):
         gp(torch.rand(1, 3, 256, 256, device=dev))
+
+
+def test_ddp_train_step_single_rank_rccl(smpl_model):
+    """The data-parallel wrapper (training.SegTrainer(ddp=True): DistributedDataParallel over RCCL, train.py:205-210's
+    multi_gpu_model) with a one-rank process group on this GPU: the hand-written autograd nodes (decoder, batch
+    norm, PReLU, loss) run under DDP's hooks, the bucketed all-reduce executes, and two steps reduce nothing to NaN."""
+    import os
+    import torch.distributed as dist
+    from ilps_amd.training import SegTrainer
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        tr = SegTrainer(smpl_model, output_wh=48, encoder_architecture="enet", use_IEF=True, device=dev, ddp=True,
+                        with_silhouette=True)
+        tr.smpl_model.train()
+        B = 2
+        images = torch.rand(B, 3, 256, 256, device=dev)
+        labels = torch.randint(0, 32, (B, 48, 48), device=dev)
+        sl = torch.nn.functional.one_hot(torch.randint(0, 2, (B, 48 * 48), device=dev), 2).float()
+        losses = [float(tr.step(images, labels, sl)) for _ in range(2)]
+        assert all(np.isfinite(losses))
+        g = [p.grad for p in tr.smpl_model.parameters() if p.grad is not None]
+        assert len(g) > 100 and all(bool(torch.isfinite(t).all()) for t in g)
+    finally:
+        dist.destroy_process_group()
