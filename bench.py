@@ -322,6 +322,21 @@ def main():
             stages = stage_breakdown(x, consts, pt, W)
             line["stages_us"] = stages
             line["stage_rooflines"] = stage_rooflines(stages, B, W, consts.V, ops.blend_gemm_mode())
+            # the whole step as a stream: HBM-side bytes of its kernels from the committed PMC passes (B = 128, W = 48)
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tfile) and B == 128 and W == 48:
+                try:
+                    ks = json.load(open(tfile))["kernels"]
+                    tot = sum(v.get("hbm_bytes_per_launch", 0) for k, v in ks.items()
+                              if "pack" not in k and "copy" not in k)
+                    gbs = tot / (ms * 1e-3) / 1e9
+                    line["step_hbm"] = {"bound": "hbm", "traffic": int(tot), "achieved": round(gbs, 1),
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                        "note": "PMC FETCH_SIZE/WRITE_SIZE bytes of the step's 9 kernels (profiles/"
+                                                "pmc_traffic.json) / graph step time: a chain of launch- and "
+                                                "latency-bound kernels at B = 128, not a bandwidth-bound stream"}
+                except Exception:
+                    pass
             t_seg = stages["vis_seg_fwd"] * 1e-6
             flop = SEG_FWD_FLOP_PER_MESH * B if W == 48 else (W * W * 6879 * 7 + W * W * 62) * B
             ach = flop / t_seg / 1e12
