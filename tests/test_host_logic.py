@@ -108,3 +108,38 @@ def test_shard_range():
         assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_batch_norm_dispatch_falls_back_to_stock_modules_on_cpu():
+    """ops.batch_norm_act / batch_norm_residual_act route to the HIP kernels only for training-mode fp32 HIP
+    tensors; on the CPU (and in eval mode) they are exactly the stock modules' composition."""
+    import copy
+    import torch
+    from ilps_amd import ops
+    from ilps_amd.model import PReLU
+    torch.manual_seed(0)
+    x, other = torch.randn(3, 5, 20, 20), torch.randn(3, 5, 20, 20)
+    bn, act = torch.nn.BatchNorm2d(5, eps=1e-3, momentum=0.1).train(), PReLU(5)
+    bn2 = copy.deepcopy(bn)
+    want = act(bn2(x))
+    got = ops.batch_norm_act(x, bn, act)
+    assert torch.equal(got, want) and torch.equal(bn.running_mean, bn2.running_mean)
+    assert int(bn.num_batches_tracked) == 1
+    drop = torch.nn.Dropout2d(0.0)
+    want2 = act(drop(bn2(x)) + other)
+    got2 = ops.batch_norm_residual_act(x, bn, drop, other, act)
+    assert torch.equal(got2, want2)
+    bn.eval(); bn2.eval()
+    assert torch.equal(ops.batch_norm_act(x, bn), bn2(x))
+
+
+def test_blend_gemm_mode_env(monkeypatch):
+    import pytest
+    from ilps_amd import ops
+    monkeypatch.delenv("SMPLR_BLEND_GEMM", raising=False)
+    assert ops.blend_gemm_mode() == "bf16x3"
+    monkeypatch.setenv("SMPLR_BLEND_GEMM", "f32")
+    assert ops.blend_gemm_mode() == "f32"
+    monkeypatch.setenv("SMPLR_BLEND_GEMM", "fp16")
+    with pytest.raises(RuntimeError):
+        ops.blend_gemm_mode()
