@@ -143,3 +143,32 @@ def test_blend_gemm_mode_env(monkeypatch):
     monkeypatch.setenv("SMPLR_BLEND_GEMM", "fp16")
     with pytest.raises(RuntimeError):
         ops.blend_gemm_mode()
+
+
+def test_part_tables_match_the_reference_coloured_template():
+    """The reference ships the 31-part partition twice: as vertex-id lists (keras_smpl/part_vertices.pkl, what
+    projects_to_seg.py:18-24 reads -> data/part_tables.npz) and as per-vertex colours of template-bodyparts.ply
+    (-> tests/golden/ply_vertex_colour_class.npz, colour classes only).  They must describe the same partition:
+    one colour per part, and the 11 vertices that belong to no part share a 32nd colour (grey)."""
+    import os
+    from ilps_amd.smpl_model import load_part_tables
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ply_vertex_colour_class.npz"))
+    cls, colours = g["vertex_class"].astype(np.int64), g["colours"]
+    assert cls.shape == (6890,) and colours.shape == (32, 3)
+    ids, off = load_part_tables(1)
+    part = np.full(6890, -1)
+    for p in range(31):
+        part[ids[off[p]:off[p + 1]]] = p
+    assert int((part < 0).sum()) == 11
+    seen = {}
+    for p in range(-1, 31):
+        c = np.unique(cls[part == p])
+        assert len(c) == 1, "part %d carries %d colours" % (p, len(c))
+        seen[p] = int(c[0])
+    assert len(set(seen.values())) == 32                       # a bijection between parts (+ unassigned) and colours
+    assert tuple(colours[seen[-1]]) == (191, 191, 191)
+    # the sampled tables are the same partition restricted to every 2nd / 5th vertex
+    for vs in (2, 5):
+        ids_s, off_s = load_part_tables(vs)
+        for p in range(31):
+            assert np.all(part[ids_s[off_s[p]:off_s[p + 1]]] == p)

@@ -8,7 +8,13 @@ Inputs (data only, read from the read-only reference mount; never source code):
       'shape' float64[10] at byte 4192, 'pose' float64[72] at byte 4272
       (read through deepdish at set_cam_params.py:41-47, concat_mean_param.py:9-15)
 
-Output: indirect_learning_pose-shape_amd/data/part_tables.npz, mean_params.npz
+  template-bodyparts.ply
+      the template mesh coloured by body part (the renderer's asset, renderer.py): 6890 vertices with an RGB
+      colour each.  Only the COLOUR CLASS of every vertex is kept (no geometry): an independent statement of
+      the 31-part partition, used by tests/test_host_logic.py to pin the part tables.
+
+Output: indirect_learning_pose-shape_amd/data/part_tables.npz, mean_params.npz,
+        tests/golden/ply_vertex_colour_class.npz
 
 The pickles are parsed with an unpickler that refuses every global (they hold
 only INT/LIST opcodes), so nothing from the mount is ever executed.
@@ -67,6 +73,19 @@ def main():
     assert abs(shape[0] - 0.20560974) < 1e-7
     np.savez(os.path.join(OUT, "mean_params.npz"), shape=shape, pose=pose)
     print("mean shape[:3]", shape[:3], "pose[:6]", pose[:6])
+
+    # template-bodyparts.ply: binary little-endian, vertex = 6 floats (position, normal) + 3 uchar (colour)
+    with open(os.path.join(REF, "template-bodyparts.ply"), "rb") as f:
+        raw = f.read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"element vertex 6890" in head and b"format binary_little_endian" in head
+    dt = np.dtype([("pos", "<f4", 3), ("nrm", "<f4", 3), ("rgb", "u1", 3)])
+    v = np.frombuffer(body[:6890 * dt.itemsize], dtype=dt)
+    colours, cls = np.unique(v["rgb"], axis=0, return_inverse=True)
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+    np.savez_compressed(os.path.join(golden, "ply_vertex_colour_class.npz"), colours=colours.astype(np.uint8),
+                        vertex_class=cls.astype(np.uint8))
+    print("ply: %d colour classes over %d vertices" % (len(colours), len(cls)))
 
 
 if __name__ == "__main__":
