@@ -55,6 +55,67 @@ class SegTrainer:
     def state_dict(self):                                           # train.py:302-315 saves smpl_model only
         return self.smpl_model.state_dict()
 
+    # ---- save / resume (train.py:181-193 `resume_from`, :300-315 `smpl_model.save`) -------------------------
+    def save(self, path, trial=0):
+        """The regressor's weights (what the reference saves), plus what a bit-exact resume of THIS trainer also
+        needs and Keras' `model.save` would have kept: the Adam state, and the trial counter."""
+        torch.save({"smpl_model": self.smpl_model.state_dict(), "optimizer": self.opt.state_dict(),
+                    "trial": int(trial), "output_wh": int(self.output_wh)}, path)
+
+    def resume(self, path):
+        """-> the trial to continue from.  A file holding only a state dict (weights) is accepted too."""
+        ck = torch.load(path, map_location=self.device)
+        if "smpl_model" not in ck:
+            self.smpl_model.load_state_dict(ck)
+            return 0
+        if int(ck.get("output_wh", self.output_wh)) != int(self.output_wh):
+            raise RuntimeError("checkpoint was trained at %dx%d, this trainer renders %dx%d"
+                               % (ck["output_wh"], ck["output_wh"], self.output_wh, self.output_wh))
+        self.smpl_model.load_state_dict(ck["smpl_model"])
+        self.opt.load_state_dict(ck["optimizer"])
+        return int(ck.get("trial", -1)) + 1
+
+
+def save_name(dataset, output_wh, use_IEF=True, scaledown=0.005, vertex_sampling=None, weight_classes=True, trial=0,
+              encoder="resnet"):
+    """The reference's checkpoint file name (train.py:302-313), with torch's extension."""
+    name = "%s_%dx%d_%s" % (dataset, output_wh, output_wh, encoder)
+    if use_IEF:
+        name += "_ief"
+    name += "_scaledown" + str(scaledown).replace(".", "")
+    if vertex_sampling is not None:
+        name += "_vs%d" % vertex_sampling
+    if weight_classes:
+        name += "_arms_weighted_2_bg_weighted_0point3_gamma2_multigpu"
+    return name + "_%d.pt" % trial
+
+
+def fit(trainer, batches, trials, steps_per_trial, save_dir=None, save_every=10, name_fn=None, start_trial=0,
+        on_trial_end=None):
+    """The loop of train.py:221-315: `trials` rounds of `steps_per_trial` optimiser steps (`fit_generator(...,
+    steps_per_epoch, nb_epoch=1)`) over `batches` - an iterator of (images, labels[, silhouette labels]) already
+    on the device, the data generators being the caller's - and every `save_every` trials (on rank 0) the monitor
+    hook and a checkpoint named like the reference's.  -> list of per-trial mean losses (python floats; the one
+    host sync per trial)."""
+    it = iter(batches)
+    rank0 = (not dist.is_initialized()) or dist.get_rank() == 0
+    history = []
+    for trial in range(start_trial, trials):
+        total = None
+        for _ in range(steps_per_trial):
+            batch = next(it)
+            loss = trainer.step(*batch)
+            total = loss if total is None else total + loss
+        history.append(float(total) / max(1, steps_per_trial))
+        if trial % save_every == 0:
+            if on_trial_end is not None and rank0:
+                on_trial_end(trial, trainer)
+            if save_dir is not None and rank0:
+                os.makedirs(save_dir, exist_ok=True)
+                fname = name_fn(trial) if name_fn is not None else "smpl_model_%d.pt" % trial
+                trainer.save(os.path.join(save_dir, fname), trial)
+    return history
+
 
 def init_distributed():
     """Rank/world from torchrun's environment; RCCL over xGMI on GPUs, gloo on CPU."""

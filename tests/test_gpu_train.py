@@ -239,3 +239,36 @@ def test_ddp_train_step_single_rank_rccl(smpl_model):
         assert len(g) > 100 and all(bool(torch.isfinite(t).all()) for t in g)
     finally:
         dist.destroy_process_group()
+
+
+def test_fit_loop_saves_and_resumes(smpl_model, tmp_path):
+    """training.fit (train.py:221-315's trial loop) writes checkpoints under the reference's naming scheme, and
+    SegTrainer.resume restores weights, Adam state and the trial counter exactly."""
+    import itertools
+    import os
+    from ilps_amd.training import SegTrainer, fit, save_name
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    tr = SegTrainer(smpl_model, output_wh=48, encoder_architecture="enet", use_IEF=True, device=dev)
+    tr.smpl_model.train()
+    B = 2
+    images = torch.rand(B, 3, 256, 256, device=dev)
+    labels = torch.randint(0, 32, (B, 48, 48), device=dev)
+    name = lambda t_: save_name("up-s31", 48, True, 0.005, None, True, t_, encoder="enet")
+    assert name(10) == "up-s31_48x48_enet_ief_scaledown0005_arms_weighted_2_bg_weighted_0point3_gamma2_multigpu_10.pt"
+    seen = []
+    hist = fit(tr, itertools.repeat((images, labels)), trials=3, steps_per_trial=2, save_dir=str(tmp_path), save_every=2,
+               name_fn=name, on_trial_end=lambda t_, _tr: seen.append(t_))
+    assert len(hist) == 3 and all(np.isfinite(hist)) and seen == [0, 2]
+    assert sorted(os.listdir(tmp_path)) == sorted([name(0), name(2)])
+    want = {k: v.clone() for k, v in tr.smpl_model.state_dict().items()}
+    step_count = [int(st["step"]) for st in tr.opt.state_dict()["state"].values()][:1]
+    tr2 = SegTrainer(smpl_model, output_wh=48, encoder_architecture="enet", use_IEF=True, device=dev)
+    nxt = tr2.resume(os.path.join(tmp_path, name(2)))
+    assert nxt == 3
+    got = tr2.smpl_model.state_dict()
+    assert all(torch.equal(got[k], want[k]) for k in want)
+    assert [int(st["step"]) for st in tr2.opt.state_dict()["state"].values()][:1] == step_count
+    with pytest.raises(RuntimeError):
+        SegTrainer(smpl_model, output_wh=64, encoder_architecture="enet", use_IEF=True, device=dev).resume(
+            os.path.join(tmp_path, name(2)))
