@@ -430,6 +430,31 @@ def main():
                 del reg, dec1, img
             except Exception as e:
                 line["aux"]["predict_B1"] = {"error": str(e)}
+            # the reference's own renderer-profiling workload (profiling_renderer.py:19-39): ONE sample of 6890 uniform
+            # random vertices x 80, compute_mask over all of them, projects_to_seg at 48x48 with vertex_sampling = 5
+            # (which gathers positions ids // 5 of the 6890-long list, i.e. from its first 1378 rows), forward only
+            try:
+                g5 = torch.Generator(device="cpu").manual_seed(5)
+                pr = (torch.rand(1, 6890, 3, generator=g5) * 80.0).to(dev)
+                pt5 = ops.get_part_table(5, dev, consts.V)
+
+                def ref_recipe():
+                    mk = ops.visibility(pr)
+                    return ops._seg_fwd(pr[:, :pt5.VP].contiguous(), mk[:, :pt5.VP].contiguous(), 48, pt5)
+                ref_recipe()
+                t_r = graph_time_ms(ref_recipe, 10, torch.cuda.current_stream())
+                entry = {"gpu_us": round(t_r * 1e3, 1), "batch": 1, "img_wh": 48, "vertex_sampling": 5}
+                if world == 1 and not args.no_cpu_baseline:
+                    from oracle import np_oracle as no_
+                    ids5, off5 = load_part_tables(5)
+                    pj5 = pr.cpu().numpy().astype(np.float64)
+                    t0c = time.perf_counter()
+                    mk5 = no_.compute_mask(pj5)
+                    no_.projects_to_seg(pj5[:, :pt5.VP], mk5[:, :pt5.VP], 48, ids5, off5, 5)
+                    entry["cpu_port_ms"] = round((time.perf_counter() - t0c) * 1e3, 1)
+                line["aux"]["reference_renderer_profile_workload"] = entry
+            except Exception as e:
+                line["aux"]["reference_renderer_profile_workload"] = {"error": str(e)}
             # silhouette rasteriser (part of configs[4]'s second loss), same meshes
             c0s = ops._pose_fwd(x, 4, consts)
             pjs = ops._skin_fwd(ops._blend_fwd(c0s[0], consts, x.shape[0]), c0s[3], consts, cam=x)[1]
