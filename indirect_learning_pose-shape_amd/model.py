@@ -193,7 +193,7 @@ class FullModel(nn.Module):
     model.py:119-120), 'segs_raw' ((N,W,W,32), the predict path model.py:176-184), 'smpl', 'verts',
     'projects', or 'all' (dict)."""
 
-    def __init__(self, smpl_model: SMPLRegressor, decoder: SMPLDecoder, output="segs"):
+    def __init__(self, smpl_model, decoder: SMPLDecoder, output="segs"):
         super().__init__()
         self.smpl_model, self.decoder, self.output = smpl_model, decoder, output
 
@@ -223,6 +223,33 @@ def build_model(train_batch_size, input_shape, smpl_path, output_wh, num_classes
         raise ValueError("the decoder produces 32 classes (31 parts + background)")
     smpl_model = SMPLRegressor(output_wh, encoder_architecture, use_IEF, scaledown)
     decoder = SMPLDecoder(smpl_path, img_wh=output_wh, vertex_sampling=vertex_sampling)
+    return (FullModel(smpl_model, decoder, "segs"), smpl_model, FullModel(smpl_model, decoder, "verts"),
+            FullModel(smpl_model, decoder, "projects"))
+
+
+class EmbeddedSMPLParams(nn.Module):
+    """The "encoder" of decoder_loss_debugging.py:69-77: one learnable 86-vector per sample index
+    (`Embedding(25, 86)`, Keras' uniform(-0.05, 0.05) initialiser) + `load_mean_set_cam_params`."""
+
+    def __init__(self, output_wh, num_embeddings=25):
+        super().__init__()
+        self.output_wh = output_wh
+        self.table = nn.Embedding(num_embeddings, 86)
+        nn.init.uniform_(self.table.weight, -0.05, 0.05)
+
+    def forward(self, index_inputs):
+        idx = index_inputs.reshape(index_inputs.shape[0]).long()
+        return load_mean_set_cam_params(self.table(idx), self.output_wh)
+
+
+def build_debug_model(batch_size, smpl_path, output_img_wh, num_classes, vertex_sampling=None):
+    """`build_debug_model`, decoder_loss_debugging.py:69-100: the decoder driven by a table of learnable SMPL
+    parameters instead of an image encoder - fitting it to target segmentations exercises nothing but the
+    decoder's forward and backward.  Returns (segs_model, smpl_model, verts_model, projects_model) on index inputs."""
+    if num_classes != 32:
+        raise ValueError("the decoder produces 32 classes (31 parts + background)")
+    smpl_model = EmbeddedSMPLParams(output_img_wh)
+    decoder = SMPLDecoder(smpl_path, img_wh=output_img_wh, vertex_sampling=vertex_sampling)
     return (FullModel(smpl_model, decoder, "segs"), smpl_model, FullModel(smpl_model, decoder, "verts"),
             FullModel(smpl_model, decoder, "projects"))
 

@@ -272,3 +272,56 @@ def test_fit_loop_saves_and_resumes(smpl_model, tmp_path):
     with pytest.raises(RuntimeError):
         SegTrainer(smpl_model, output_wh=64, encoder_architecture="enet", use_IEF=True, device=dev).resume(
             os.path.join(tmp_path, name(2)))
+
+
+def test_decoder_loss_debugging_fit(smpl_model):
+    """decoder_loss_debugging.py's experiment: no encoder, a table of learnable SMPL parameters (`build_debug_model`)
+    fitted by Adam through the decoder to target part maps with `categorical_focal_loss(gamma=5)`.  Starting from
+    the mean pose the loss must fall and the rendered part maps must move towards the targets - the hand-written
+    backward of every kernel on the path is what makes that happen."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.focal_loss import softmax_focal_loss
+    from ilps_amd.model import build_debug_model
+    from ilps_amd.smpl_model import mean86
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n, W = 4, 48
+    segs_model, params_model, verts_model, projects_model = build_debug_model(n, smpl_model, W, 32)
+    for m in (segs_model, params_model):
+        m.to(dev)
+    # targets: part maps of perturbed poses / shapes / cameras
+    g = torch.Generator().manual_seed(3)
+    xt = torch.tensor(np.tile(mean86(W), (n, 1)), dtype=torch.float32)
+    xt[:, 4:76] += 0.25 * torch.randn(n, 72, generator=g)
+    xt[:, 76:] += 0.8 * torch.randn(n, 10, generator=g)
+    xt[:, 2:4] += 2.0 * torch.randn(n, 2, generator=g)
+    with torch.no_grad():
+        target = SMPLDecoder(smpl_model, img_wh=W)(xt.to(dev))["seg"].argmax(-1)            # (n, W, W)
+    idx = torch.arange(n, device=dev).reshape(n, 1)
+    loss_fn = softmax_focal_loss(5.0, False)                       # gamma = 5, as the script compiles it
+    opt = torch.optim.Adam(params_model.parameters(), lr=0.02)
+    dec = segs_model.decoder
+
+    def render():
+        return dec(params_model(idx))["seg"]
+
+    def agreement():
+        with torch.no_grad():
+            pm = render().argmax(-1)
+            fg = target > 0
+            return float(((pm == target) & fg).sum()) / float(fg.sum())
+    a0 = agreement()
+    losses = []
+    for _ in range(150):
+        opt.zero_grad(set_to_none=True)
+        loss = loss_fn(target, render()).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    a1 = agreement()
+    print("loss %.4f -> %.4f, foreground part agreement %.3f -> %.3f" % (losses[0], losses[-1], a0, a1))
+    # (the softmax runs over scores in [0, 1], so the loss has a high floor: the reference's design, model.py:119-120)
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.1, (losses[0], losses[-1])
+    assert a1 > a0 + 0.1, "foreground part agreement %.3f -> %.3f" % (a0, a1)
+    assert verts_model(idx).shape == (n, 6890, 3) and projects_model(idx).shape == (n, 6890, 3)
+    assert segs_model(idx).shape == (n, W * W, 32)
