@@ -17,7 +17,7 @@ from .keras_smpl.batch_smpl import _resolve_model
 
 class SMPLDecoder(nn.Module):
     def __init__(self, smpl_path=None, img_wh=48, vertex_sampling=None, num_cam=4, grid_wh=64,
-                 ref_compat=True, with_silhouette=False, streams=1):
+                 ref_compat=True, with_silhouette=False, streams=1, silh_wh=None):
         super().__init__()
         self._model = _resolve_model(smpl_path)
         self.img_wh = int(img_wh)
@@ -27,6 +27,8 @@ class SMPLDecoder(nn.Module):
                              "(projects_to_silhouette.py:33): no vertex sampling")
         self.num_cam, self.grid_wh, self.ref_compat = int(num_cam), int(grid_wh), bool(ref_compat)
         self.with_silhouette = bool(with_silhouette)
+        # the silhouette may have its own resolution (train_stage2_silhouette.py:72-86: `silhs_output_wh`)
+        self.silh_wh = int(silh_wh) if silh_wh is not None else self.img_wh
         self.streams = int(streams)      # concurrent mesh chunks (HIP streams); results do not depend on it
         self._consts = None
         self._dev = None
@@ -45,7 +47,7 @@ class SMPLDecoder(nn.Module):
         pt = ops.get_part_table(self.vs, x.device, c.V)
         verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(
             x, c, self.num_cam, self.img_wh, self.vs, pt, self.grid_wh, self.ref_compat,
-            self.with_silhouette, self.streams)
+            (True if self.silh_wh == self.img_wh else self.silh_wh) if self.with_silhouette else False, self.streams)
         out = dict(verts=verts, projects=proj, mask=mask, seg=seg, J_transformed=jt)
         if self.with_silhouette:
             out["silhouette"] = silh

@@ -211,6 +211,9 @@ class FullModel(nn.Module):
             return out["projects"]
         if self.output == "segs_raw":
             return out["seg"]
+        if self.output == "silhs":                     # train_stage2_silhouette.py:85-86
+            sil = out["silhouette"]
+            return torch.softmax(sil.reshape(sil.shape[0], -1, sil.shape[-1]), dim=-1)
         seg = out["seg"]
         return torch.softmax(seg.reshape(seg.shape[0], -1, seg.shape[-1]), dim=-1)
 
@@ -252,6 +255,18 @@ def build_debug_model(batch_size, smpl_path, output_img_wh, num_classes, vertex_
     decoder = SMPLDecoder(smpl_path, img_wh=output_img_wh, vertex_sampling=vertex_sampling)
     return (FullModel(smpl_model, decoder, "segs"), smpl_model, FullModel(smpl_model, decoder, "verts"),
             FullModel(smpl_model, decoder, "projects"))
+
+
+def build_full_model_from_saved_model_stage2(smpl_model, segs_output_wh, silhs_output_wh, smpl_path, batch_size,
+                                             num_classes_segs=32, num_classes_silhs=2):
+    """`build_full_model_from_saved_model` of train_stage2_silhouette.py:72-104: around a saved encoder, the part
+    segmentation at `segs_output_wh` and the silhouette at its own `silhs_output_wh` from ONE decoder pass.
+    Returns (verts_model, projects_model, silhouettes_model, segs_model)."""
+    if num_classes_segs != 32 or num_classes_silhs != 2:
+        raise ValueError("the decoder produces 32 part classes and 2 silhouette classes")
+    decoder = SMPLDecoder(smpl_path, img_wh=segs_output_wh, with_silhouette=True, silh_wh=silhs_output_wh)
+    return (FullModel(smpl_model, decoder, "verts"), FullModel(smpl_model, decoder, "projects"),
+            FullModel(smpl_model, decoder, "silhs"), FullModel(smpl_model, decoder, "segs"))
 
 
 def build_full_model_from_saved_model(smpl_model, output_wh, smpl_path, batch_size, num_classes):

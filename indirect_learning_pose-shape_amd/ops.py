@@ -697,6 +697,9 @@ class DecoderFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         vs, W, B = int(vertex_sampling), int(img_wh), x.shape[0]
+        # with_silh: False = no silhouette; True = at img_wh; an int = its own resolution
+        # (train_stage2_silhouette.py:72-86 renders the silhouettes at `silhs_output_wh`)
+        Ws = 0 if not with_silh else (W if with_silh is True else int(with_silh))
         V, VP = consts.V, (consts.V + vs - 1) // vs
         Rs, J = _empty((B, 24, 9), x), _empty((B, 24, 3), x)
         A, Jt = _empty((B, 24, 12), x), _empty((B, 24, 3), x)
@@ -706,7 +709,7 @@ class DecoderFn(torch.autograd.Function):
         rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), x)
         vslot = _empty((B, VP), x, torch.int16)
         if with_silh:
-            silh, sarg = _empty((B, W, W, 2), x), _empty((B, W, W), x, torch.int32)
+            silh, sarg = _empty((B, Ws, Ws, 2), x), _empty((B, Ws, Ws), x, torch.int32)
         else:
             silh = sarg = torch.empty(0, device=x.device)
 
@@ -719,12 +722,13 @@ class DecoderFn(torch.autograd.Function):
             _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,
                          out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
             if with_silh:
-                _silh_fwd(proj[lo:hi], W, out=(silh[lo:hi], sarg[lo:hi]))
+                _silh_fwd(proj[lo:hi], Ws, out=(silh[lo:hi], sarg[lo:hi]))
 
         bounds = _chunk_bounds(B, nchunk)
         if B > 0:
             _run_chunks(bounds, x.device, run)
-        ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, with_silh
+        ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, bool(with_silh)
+        ctx.Ws = Ws
         ctx.bounds = bounds
         ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot)
         ctx.mark_non_differentiable(mask)
@@ -748,7 +752,7 @@ class DecoderFn(torch.autograd.Function):
                 part, nsplit = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt, merge=False)
                 seg_grad = (part, vslot[lo:hi], nsplit)
             if dsilh is not None:
-                d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.W)
+                d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.Ws)
                 dproj = d2 if dproj is None else dproj + d2
             if dproj_in is not None:
                 dproj = dproj_in[lo:hi] if dproj is None else dproj + dproj_in[lo:hi]

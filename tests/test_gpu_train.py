@@ -325,3 +325,22 @@ def test_decoder_loss_debugging_fit(smpl_model):
     assert a1 > a0 + 0.1, "foreground part agreement %.3f -> %.3f" % (a0, a1)
     assert verts_model(idx).shape == (n, 6890, 3) and projects_model(idx).shape == (n, 6890, 3)
     assert segs_model(idx).shape == (n, W * W, 32)
+
+
+def test_stage2_models_silhouette_at_its_own_resolution(smpl_model):
+    """train_stage2_silhouette.py:72-104: segs at 48x48 and silhouettes at 64x64 from one decoder pass; the
+    silhouette equals projects_to_silhouette on the same projection, and both heads send gradient to the encoder."""
+    from ilps_amd.keras_smpl.projects_to_silhouette import projects_to_silhouette
+    from ilps_amd.model import SMPLRegressor, build_full_model_from_saved_model_stage2
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    reg = SMPLRegressor(48, "enet", True).to(dev).eval()
+    verts_m, proj_m, silh_m, segs_m = build_full_model_from_saved_model_stage2(reg, 48, 64, smpl_model, 2)
+    img = torch.rand(2, 3, 256, 256, device=dev)
+    sil, seg, pr = silh_m(img), segs_m(img), proj_m(img)
+    assert sil.shape == (2, 64 * 64, 2) and seg.shape == (2, 48 * 48, 32)
+    want = torch.softmax(projects_to_silhouette(pr.detach(), 64).reshape(2, -1, 2), -1)
+    assert torch.allclose(sil, want, atol=1e-6)
+    (sil[..., 1].sum() + seg[..., 5].sum()).backward()
+    g = reg.IEF_layer_3.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
