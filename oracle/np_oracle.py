@@ -10,7 +10,9 @@ Keras 2.1 (versions named only in README.md:19-27, no lock file) and it cannot b
 (`import cPickle`, `import tensorflow` raise ModuleNotFoundError; the SMPL pkl it opens is
 absent).  This file is therefore a restatement written from the source text, op for op in the
 reference's order, pinned by the analytic known-answer tests in `tests/test_oracle_kat.py`
-and the golden vectors it generated itself (`tests/golden/`, `tools/make_golden.py`).
+and the golden vectors it generated itself (`tests/golden/`, `tools/make_golden.py`).  The DATA it reads
+is the reference's own (part tables from keras_smpl/*part_vertices.pkl, cross-checked against the colour
+classes of template-bodyparts.ply; mean pose / shape from neutral_smpl_mean_params.h5: tools/make_fixtures.py).
 
 Every function cites the reference lines it follows (paths relative to the reference root).
 """
