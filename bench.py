@@ -463,6 +463,20 @@ def main():
             t_sf = event_time_ms(lambda: ops._silh_fwd(pjs, W), 20, torch.cuda.current_stream())
             t_sb = event_time_ms(lambda: ops._silh_bwd(dsil, sil, sarg, pjs, W), 20, torch.cuda.current_stream())
             line["aux"]["silhouette"] = {"fwd_us": round(t_sf * 1e3, 2), "bwd_us": round(t_sb * 1e3, 2), "meshes": B}
+            # the decoder of configs[4]: part segmentation AND silhouette from one pass, fwd+bwd of both heads
+            try:
+                dsl = torch.randn(B, W, W, 2, device=dev)
+
+                def step_silh():
+                    xg = x.detach().requires_grad_(True)
+                    _v, _p, _m, sg_, sl_, _j = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, True, 1)
+                    torch.autograd.backward([sg_, sl_], [dseg, dsl])
+                step_silh()
+                t_ds = graph_time_ms(step_silh, 5, torch.cuda.current_stream())
+                line["aux"]["decoder_with_silhouette"] = {"ms_per_step": round(t_ds, 4),
+                                                          "meshes_per_s": round(B / (t_ds * 1e-3), 1)}
+            except Exception as e:
+                line["aux"]["decoder_with_silhouette"] = {"error": str(e)}
             # loss head: softmax + focal loss on the (B,W,W,32) scores, HBM-bound.
             # algorithmic bytes: fwd = scores 128 + label 4 + loss 4 B/pixel; bwd = 128 + 4 + 4 + 128 B/pixel
             seg_s = torch.rand(B, W, W, 32, device=dev)
