@@ -728,6 +728,34 @@ def test_seg_gradient_gathered_by_vertex_equals_merged(layer, smpl_model, vs, W,
     assert torch.allclose(d1, dproj, rtol=1e-4, atol=1e-6)
 
 
+def test_pose_kernels_generic_tree_fallback(smpl_model):
+    """The pose kernels run the kinematic chain by tree level when `parents` is the standard SMPL tree (a wave
+    checks) and serially for any other tree: a model whose joints form one long chain (parent[i] = i - 1) and one
+    with a wide tree must still match the float64 oracle, forward and backward."""
+    import copy
+    from ilps_amd.keras_smpl.batch_smpl import SMPLLayer
+    from oracle import np_oracle as o
+    from oracle.torch_oracle import TorchSMPL
+    for parents in (np.arange(-1, 23), np.array([-1] + [0] * 7 + [1, 1, 2, 2, 3, 3, 8, 8, 9, 10, 11, 12, 13, 14, 15, 16])):
+        m = copy.deepcopy(smpl_model)
+        m.parents = parents.astype(m.parents.dtype)
+        B = 3
+        x = make_x(B, 48, seed=int(parents[5]) + 900)
+        x[:, 4:76] *= 0.3                                  # a 23-long chain compounds rotations: keep poses moderate
+        layer = SMPLLayer(m)
+        ref = o.smpl_layer_call(x.astype(np.float64), m, return_all=True)
+        xg = t(x).requires_grad_(True)
+        verts = layer(xg)
+        assert np.abs(verts.detach().cpu().numpy() - ref["verts"]).max() <= VERT_ATOL
+        rng = np.random.default_rng(1)
+        gv, gj = rng.normal(0, 1, (B, 6890, 3)), rng.normal(0, 1, (B, 24, 3))
+        ((verts * t(gv)).sum() + (layer.J_transformed * t(gj)).sum()).backward()
+        xo = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        vo, jo, _ = TorchSMPL(m)(xo, return_all=True)
+        ((vo * torch.tensor(gv)).sum() + (jo * torch.tensor(gj)).sum()).backward()
+        grad_close(xg.grad.cpu().numpy()[:, 4:], xo.grad.numpy()[:, 4:], name="dx (tree %s...)" % parents[:4])
+
+
 # ----------------------------------------------------------------------------------- BASELINE-size batches
 def test_full_size_batch_is_row_independent(smpl_model):
     """B = 160 (BASELINE configs[2] is 128; 160 = one full 128-mesh group + a ragged one, 5 mesh tiles
