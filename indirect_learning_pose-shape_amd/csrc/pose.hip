@@ -283,6 +283,13 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
   const int n = blockIdx.x;
   const bool live = true;
   const size_t nn = n;
+  // this lane's joint angles, needed only by the Rodrigues backward at the very end: requested with everything
+  // else (a load there sat alone on the critical path)
+  float th[3] = {0.f, 0.f, 0.f};
+  if (tid < 24) {
+    const float *xr0 = x + nn * x_stride + num_cam + 3 * tid;
+    th[0] = xr0[0]; th[1] = xr0[1]; th[2] = xr0[2];
+  }
   for (int e = tid; e < 720; e += PBW) sJd[e] = J_dirs[e];
   for (int e = tid; e < 216; e += PBW) L.Rs[e / 9][e % 9] = Rs_in[nn * 216 + e];
   for (int e = tid; e < 72; e += PBW) L.J[e / 3][e % 3] = J_in[nn * 72 + e];
@@ -362,24 +369,36 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
   if (live && lane < 9) L.dR[0][lane] = L.dGR[0][lane];
   if (live && lane >= 16 && lane < 19) L.dJ[0][lane - 16] += L.dGt[0][lane - 16];
   wave_sync();
+  // d beta = dcoef[0..9] + J_dirs^T dJ: 10 x 72 products, over 60 lanes (6 chunks of 12 per beta; the 10 serial
+  // 72-term sums took 0.6 us between two divergent branches), chunk sums parked in L.dA (free by now)
+  float *scratch = &L.dA[0][0];
+  if (live && lane < 60) {
+    const int k = lane / 6, part = lane - 6 * k;
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const int e = part * 12 + q;
+      acc += L.dJ[e / 3][e % 3] * sJd[e * 10 + k];
+    }
+    scratch[lane] = acc;
+  }
+  wave_sync();
   if (live) {
     float *dxr = dx + nn * x_stride;
-    const float *xr = x + nn * x_stride;
     const float *dc = L.dcoef;
     if (lane < 24) {
       float g[9];
 #pragma unroll
       for (int e = 0; e < 9; ++e) g[e] = L.dR[lane][e] + (lane >= 1 ? dc[10 + 9 * (lane - 1) + e] : 0.0f);
-      float t[3] = {xr[num_cam + 3 * lane], xr[num_cam + 3 * lane + 1], xr[num_cam + 3 * lane + 2]};
       float dt[3];
-      rodrigues_bwd(t, g, dt);
+      rodrigues_bwd(th, g, dt);
 #pragma unroll
       for (int k = 0; k < 3; ++k) dxr[num_cam + 3 * lane + k] = dt[k];
     } else if (lane >= 32 && lane < 42) {
       const int k = lane - 32;
       float acc = dc[k];
-#pragma unroll 8
-      for (int e = 0; e < 72; ++e) acc += L.dJ[e / 3][e % 3] * sJd[e * 10 + k];
+#pragma unroll
+      for (int part = 0; part < 6; ++part) acc += scratch[k * 6 + part];
       dxr[num_cam + 72 + k] = acc;
     } else if (lane >= 48 && lane < 48 + num_cam) {
       const int cidx = lane - 48;
