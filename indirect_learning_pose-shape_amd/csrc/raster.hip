@@ -615,23 +615,39 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
 // One row strip (a 32-lane group, lane = channel) over its W pixels for one slot window.  MW =
 // false is the standard single-window case (no window test per pixel).  The arithmetic is
 // branch-free (a masked pixel contributes kk = 0); the only divergent step is the run boundary.
-template <bool MW>
+// FAST: C == 32 and W a multiple of SB_U (the reference's sizes): no clamping, and a pixel's dseg / arg elements
+// sit at compile-time byte offsets (128 B / 64 B per pixel) from ONE address per lane and batch - the general
+// form spent 29 % of the kernel's vector instructions on 64-bit address arithmetic, in a kernel that is
+// vector-issue bound.
+template <bool MW, bool FAST>
 __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, const short *__restrict__ arg,
                                             const float4 *__restrict__ R, float *acc, size_t row0, int W, int C,
                                             int ch, float fr, int base) {
-  const int chc = min(ch, C - 1);
+  const int chc = FAST ? ch : min(ch, C - 1);
   const bool chok = ch >= 1 && ch < C;
+  const short *arow = arg + row0 * 32 + ch;                    // FAST: + 32 (c0 + u) shorts
+  const float *grow = dseg + row0 * 32 + ch;                   // FAST (C == 32): + 32 (c0 + u) floats
   int cur = -1;
   float sx = 0.0f, sy = 0.0f;
   for (int c0 = 0; c0 < W; c0 += SB_U) {
     int a[SB_U];
     float g[SB_U];
+    if (FAST) {
+      const short *ab = arow + c0 * 32;
+      const float *gb = grow + c0 * 32;
 #pragma unroll
-    for (int u = 0; u < SB_U; ++u) {
-      const int cc = (c0 + u < W) ? c0 + u : W - 1;
-      const size_t po = row0 + cc;
-      a[u] = arg[po * 32 + ch];
-      g[u] = dseg[po * C + chc];                  // unconditional load (slots >= C are masked below)
+      for (int u = 0; u < SB_U; ++u) {
+        a[u] = ab[u * 32];
+        g[u] = gb[u * 32];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) {
+        const int cc = (c0 + u < W) ? c0 + u : W - 1;
+        const size_t po = row0 + cc;
+        a[u] = arg[po * 32 + ch];
+        g[u] = dseg[po * C + chc];                // unconditional load (slots >= C are masked below)
+      }
     }
     float4 rv[SB_U];
 #pragma unroll
@@ -639,7 +655,7 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       const int gate = __shfl(a[u], 0, 32);       // channel-0 lane of this pixel: 1 = clip passes gradient
       const float g0 = __shfl(g[u], 0, 32);
       g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
-      if (!(chok && c0 + u < W)) a[u] = -1;
+      if (!(chok && (FAST || c0 + u < W))) a[u] = -1;
       if (MW) {
         a[u] -= base;                             // another window's slot -> masked
         if (a[u] >= SB_SLOTS) a[u] = -1;
@@ -698,8 +714,10 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
     for (int i = tid; i < nsl * 2; i += 256) acc[i] = 0.0f;
     __syncthreads();
     if (ro < W) {
-      if (nwin == 1) seg_bwd_row<false>(dseg, arg, R, acc, row0, W, C, ch, fr, 0);
-      else seg_bwd_row<true>(dseg, arg, R, acc, row0, W, C, ch, fr, base);
+      const bool fast = C == 32 && W % SB_U == 0;           // block-uniform
+      if (nwin == 1 && fast) seg_bwd_row<false, true>(dseg, arg, R, acc, row0, W, C, ch, fr, 0);
+      else if (nwin == 1) seg_bwd_row<false, false>(dseg, arg, R, acc, row0, W, C, ch, fr, 0);
+      else seg_bwd_row<true, false>(dseg, arg, R, acc, row0, W, C, ch, fr, base);
     }
     __syncthreads();
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
