@@ -429,7 +429,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
                                                              const int *__restrict__ lstart,
                                                              const uint2 *__restrict__ lrec, int P, int K,
                                                              int S, int W, int B, int ntiles,
-                                                             float *__restrict__ seg, short *__restrict__ arg) {
+                                                             float *__restrict__ seg, short *__restrict__ arg,
+                                                             unsigned wmagic) {
   __shared__ float sS[NG * RTS * TLD];
   __shared__ short sA[NG * RTS * TLD];
   __shared__ float sSum[NG][RTS];
@@ -447,7 +448,9 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   const int npix = W * W;
   const int q = tile * RTS + pt;
   const int qc = q < npix ? q : npix - 1;
-  const int r = qc / W, c = qc - r * W;
+  // q / W for q < W^2 <= 25600 as a multiply and a shift (wmagic = ceil(2^24 / W), exact there): the
+  // compiler's sequence for a division by a run-time W is ~20 instructions, three times per lane
+  const int r = (int)(((unsigned)qc * wmagic) >> 24), c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
   const float4 *Gn = G + (size_t)n * S;
   const int *goffn = goff + (size_t)n * (P + 2);
@@ -570,8 +573,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     const int pl = pw * 64 + e / Q4, c4 = (e % Q4) * 4;
     const int qq = tile * RTS + pl;
     if (qq < npix && ch0 + c4 < C) {
-      const int rr = qq / W, cc = qq - rr * W;
-      const size_t o = ((size_t)n * W + (W - 1 - rr)) * W + cc;     // rows flipped (:68)
+      const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
+      const size_t o = (size_t)n * npix + (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68)
       const float *ts = &sS[(g * RTS + pl) * TLD + c4];
       const short *ta = &sA[(g * RTS + pl) * TLD + c4];
       float *so = seg + o * C + ch0 + c4;
@@ -1155,7 +1158,7 @@ static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fus
   const int ntiles = (W * W + RTS - 1) / RTS;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
   hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RTS * NG), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
-                     seg, reinterpret_cast<short *>(arg));
+                     seg, reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W));
   SMPLR_LAUNCH_CHECK(fn);
   return 0;
 }
