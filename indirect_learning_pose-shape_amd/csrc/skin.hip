@@ -234,12 +234,18 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     // overlaps the barrier; asked for at the top they cost 32 live registers = one wave per SIMD).
     float wa0[16], wa1[16];
     {
+      // buffer loads: a 128-bit descriptor of the weight table (wave-uniform) + ONE 32-bit byte offset per lane
+      // + an immediate per step, rows past the end of the table read as 0 (the hardware's range check; their
+      // vertices carry g = 0 anyway) - instead of a clamp and a 64-bit multiply-add per request (a fifth of
+      // the kernel's vector instructions)
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
       const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
+      const int o0 = (vb * 24 + li) * 4, o1 = (vb * 24 + 16 + (li & 7)) * 4;
   #pragma unroll
       for (int sI = 0; sI < 16; ++sI) {
-        const float *wr = lbs + (size_t)min(vb + 4 * sI, V - 1) * 24;      // tail rows: g = 0 there
-        wa0[sI] = wr[li];
-        wa1[sI] = wr[16 + (li & 7)];
+        wa0[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o0 + sI * 384, 0, 0));
+        wa1[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o1 + sI * 384, 0, 0));
       }
     }
     sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
