@@ -624,10 +624,12 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
 // vector-issue bound.
 template <bool MW, bool FAST>
 __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, const short *__restrict__ arg,
-                                            const float4 *__restrict__ R, float *acc, size_t row0, int W, int C,
-                                            int ch, float fr, int base) {
+                                            const float4 *__restrict__ R, int rbytes, float *acc, size_t row0,
+                                            int W, int C, int ch, float fr, int base) {
   const int chc = FAST ? ch : min(ch, C - 1);
   const bool chok = ch >= 1 && ch < C;
+  const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(R), 0, rbytes, 0x00020000);
   const short *arow = arg + row0 * 32 + ch;                    // FAST: + 32 (c0 + u) shorts
   const float *grow = dseg + row0 * 32 + ch;                   // FAST (C == 32): + 32 (c0 + u) floats
   int cur = -1;
@@ -663,7 +665,9 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
         a[u] -= base;                             // another window's slot -> masked
         if (a[u] >= SB_SLOTS) a[u] = -1;
       }
-      rv[u] = R[base + max(a[u], 0)];
+      // the 16-B record of the arg-min slot as a buffer load: 32-bit offset, and slot -1 (masked) falls outside
+      // the descriptor's range and reads as zeros (kk = 0 below) - no clamp, no 64-bit address per gather
+      rv[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (base + a[u]) * 16, 0, 0));
     }
 #pragma unroll
     for (int u = 0; u < SB_U; ++u) {
@@ -718,9 +722,9 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
     __syncthreads();
     if (ro < W) {
       const bool fast = C == 32 && W % SB_U == 0;           // block-uniform
-      if (nwin == 1 && fast) seg_bwd_row<false, true>(dseg, arg, R, acc, row0, W, C, ch, fr, 0);
-      else if (nwin == 1) seg_bwd_row<false, false>(dseg, arg, R, acc, row0, W, C, ch, fr, 0);
-      else seg_bwd_row<true, false>(dseg, arg, R, acc, row0, W, C, ch, fr, base);
+      if (nwin == 1 && fast) seg_bwd_row<false, true>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0);
+      else if (nwin == 1) seg_bwd_row<false, false>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0);
+      else seg_bwd_row<true, false>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, base);
     }
     __syncthreads();
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
