@@ -335,11 +335,12 @@ __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
 __device__ __forceinline__ float fast_exp_neg(float x) { return __expf(-x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
-constexpr int NG = 4;            // channel groups = waves per 64-pixel group (8: 55.7 us, 4: 48 us)
-constexpr int HC = 32 / NG;      // channels per wave (channel group)
-constexpr int TLD = HC + 1;      // tile row stride
+constexpr int NG = 4;            // waves per 64-pixel group, each walking a contiguous range of parts (8: 55.7 us, 4: 48 us)
+constexpr int SLD = 33;          // score tile row stride (floats per pixel: 32 channels + 1, conflict-free by lane)
+constexpr int ALD = 34;          // arg tile row stride (shorts per pixel: 17 dwords)
 constexpr int RTS = 1024 / NG;   // pixels per segmentation raster block (block = 1024 threads)
 constexpr int WPT = RTS / 64;    // 64-pixel sub-tiles per block
+constexpr int PART_COST = 4;     // fixed cost of a part in the balance, in records (exp, sqrt, winner re-scan)
 constexpr int NREC = 1024;  // records of a mesh's global list that fit the block's LDS copy (16 KB)
 
 // One vertex against this lane's pixel: strict '<' keeps the first arg-min in list order.
@@ -419,11 +420,22 @@ __device__ __forceinline__ void lds_scan(const char *base, int beg, int end, f32
   }
 }
 
-// Block = 256 pixels of one mesh x 4 channel groups = 16 waves: wave (g, w) evaluates channels
-// [8g, 8g+8) for pixels [64w, 64w+64) of the tile.  What bounds this kernel at small batch is the
-// per-wave dependent chain (scalar loads -> VALU -> exp -> LDS, part after part), so the 32 channels
-// are spread over 4 waves instead of walked by one; the background channel needs the sum over all
-// parts, exchanged through LDS (fixed order).
+// Sum over each aligned group of 8 lanes, the same bits in all 8 (fixed tree: lane^1, lane^2, other quad).
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+  return v;
+}
+
+// Block = 256 pixels of one mesh x 4 part ranges = 16 waves: wave (g, w) evaluates the parts of range g
+// for pixels [64w, 64w+64) of the tile.  What bounds this kernel at small batch is the per-wave
+// dependent chain (LDS reads -> VALU -> exp -> LDS, part after part), so the parts are spread over 4
+// waves instead of walked by one.  The 4 ranges are contiguous and cut so that each holds about a
+// quarter of the mesh's visible records (the block waits for its slowest wave, and the records per
+// fixed group of 8 channels differ several-fold: a torso facing the camera against a hidden arm).
+// Scores meet in a pixel-major LDS tile; after one barrier all 16 waves write it out, and the
+// background channel comes from the sum over the tile row (fixed tree, independent of the cuts).
 __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
                                                              const int *__restrict__ goff,
                                                              const int *__restrict__ lstart,
@@ -431,9 +443,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
                                                              int S, int W, int B, int ntiles,
                                                              float *__restrict__ seg, short *__restrict__ arg,
                                                              unsigned wmagic) {
-  __shared__ float sS[NG * RTS * TLD];
-  __shared__ short sA[NG * RTS * TLD];
-  __shared__ float sSum[NG][RTS];
+  __shared__ float sS[RTS * SLD];
+  __shared__ short sA[RTS * ALD];
   __shared__ f32x4 sRec[3 * NREC / 4];   // records, field-major: u[NREC] | v[NREC] | m^2[NREC]
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   if (n >= B) return;                                    // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
-  const int g = wave / WPT, pw = wave % WPT;             // channel group, pixel sub-tile
+  const int g = wave / WPT, pw = wave % WPT;             // part range, pixel sub-tile
   const int pt = pw * 64 + lane;                         // pixel within the tile
   const int npix = W * W;
   const int q = tile * RTS + pt;
@@ -482,18 +493,26 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   // the first two local records of this pixel are fetched now and used after the pair loop
   const uint2 lr0 = lrecn[min(l0, K - 1)], lr1 = lrecn[min(l0 + 1, K - 1)];
   const f32x2 fc2 = {fc, fc}, fr2 = {fr, fr};
-  float *myS = &sS[(g * RTS + pt) * TLD];
-  short *myA = &sA[(g * RTS + pt) * TLD];
-  const int ch0 = g * HC;
+  float *myS = &sS[pt * SLD + 1];                        // indexed by part (channel = part + 1)
+  short *myA = &sA[pt * ALD + 1];
+
+  // this wave's parts [ps, pe): part p belongs to range g when the midpoint of its span in the cost
+  // prefix c[p] = offset[p] + PART_COST p falls into the g-th quarter (the cuts are monotone and cover [0, P))
+  int ps, pe;
+  {
+    const int lp = lane < P ? lane : 0;                  // P <= 31 parts
+    const int mid2 = sOff[lp] + sOff[lp + 1] + PART_COST * (2 * lp + 1);     // 2 x midpoint
+    const int total = __builtin_amdgcn_readfirstlane(sOff[P]) + PART_COST * P;
+    const unsigned long long b0 = __ballot(lane < P && 2 * mid2 < total * g);
+    const unsigned long long b1 = __ballot(lane < P && 2 * mid2 < total * (g + 1));
+    ps = (g == 0) ? 0 : __popcll(b0);
+    pe = (g == NG - 1) ? P : __popcll(b1);
+  }
 
   {
-    const int p_first = (ch0 == 0) ? 0 : ch0 - 1;
-    int beg = __builtin_amdgcn_readfirstlane(sOff[p_first < P ? p_first : P]);
-    int nxt = __builtin_amdgcn_readfirstlane(sOff[(p_first + 1) < P ? (p_first + 1) : P]);   // end of the current part
-    for (int j = 0; j < HC; ++j) {
-      const int ch = ch0 + j;
-      if (ch == 0 || ch >= C) { myS[j] = 0.0f; myA[j] = -1; continue; }
-      const int p = ch - 1;
+    int beg = __builtin_amdgcn_readfirstlane(sOff[ps]);
+    int nxt = __builtin_amdgcn_readfirstlane(sOff[(ps + 1) < P ? (ps + 1) : P]);   // end of the current part
+    for (int p = ps; p < pe; ++p) {
       const int end = nxt;
       nxt = __builtin_amdgcn_readfirstlane(sOff[(p + 2) < P ? (p + 2) : P]);   // the next part's end
       float best = INFINITY;
@@ -531,62 +550,59 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
           if (k >= end) break;
         }
       }
-      myS[j] = (best < INFINITY) ? fast_exp_neg(fast_sqrt(best)) : 0.0f;
-      myA[j] = (short)bslot;
+      myS[p] = (best < INFINITY) ? fast_exp_neg(fast_sqrt(best)) : 0.0f;
+      myA[p] = (short)bslot;
       beg = end;
     }
   }
   // merge this pixel's local records (invisible vertices that round to this pixel)
   for (int i = l0; i < l1; ++i) {
     const uint2 rec = (i == l0) ? lr0 : (i == l0 + 1) ? lr1 : lrecn[i];
-    const int ch = 1 + (int)rec.y;
-    if (ch >= ch0 && ch < ch0 + HC) {
+    const int p = (int)rec.y;
+    if (p >= ps && p < pe) {
       const float sc = fast_exp_neg(__uint_as_float(rec.x));
-      const int j = ch - ch0;
-      if (sc > myS[j]) {                                   // ties keep the earlier (global) winner
-        myS[j] = sc;
-        myA[j] = (short)(lbase + i);
+      if (sc > myS[p]) {                                   // ties keep the earlier (global) winner
+        myS[p] = sc;
+        myA[p] = (short)(lbase + i);
       }
     }
   }
-  {
-    float part = 0.0f;
-#pragma unroll
-    for (int j = 0; j < HC; ++j) part += myS[j];           // the slot of channel 0 holds 0 here
-    sSum[g][pt] = part;
-  }
   __syncthreads();
-  if (g == 0) {
-    float sum = sSum[NG - 1][pt];
+  // all 16 waves write the tile: 8 lanes per pixel, 4 channels each (coalesced 128-B / 64-B pixel rows)
+  constexpr int NIT = 8 / NG;
 #pragma unroll
-    for (int gg = NG - 2; gg >= 0; --gg) sum += sSum[gg][pt];
-    myS[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
-    myA[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): tile writes done
-  __builtin_amdgcn_wave_barrier();
-  // write this wave's 64 pixels x HC channels; lane -> (pixel, group of 4 channels)
-  constexpr int Q4 = HC / 4;
+  for (int it = 0; it < NIT; ++it) {
+    const int e = it * (RTS * NG) + tid;
+    const int pl = e >> 3, c4 = (e & 7) * 4;
+    const float *ts = &sS[pl * SLD + c4];
+    const short *ta = &sA[pl * ALD + c4];
+    float v[4];
+    short a[4];
 #pragma unroll
-  for (int it = 0; it < Q4; ++it) {
-    const int e = it * 64 + lane;
-    const int pl = pw * 64 + e / Q4, c4 = (e % Q4) * 4;
+    for (int t = 0; t < 4; ++t) {
+      const bool part_ch = c4 + t >= 1 && c4 + t < C;     // the tile holds nothing for channel 0 and slots >= C
+      v[t] = part_ch ? ts[t] : 0.0f;
+      a[t] = part_ch ? ta[t] : (short)-1;
+    }
+    const float sum = sum8_dpp((v[0] + v[1]) + (v[2] + v[3]));   // over the pixel's parts (all lanes take part)
+    if (c4 == 0) {
+      v[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
+      a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
+    }
     const int qq = tile * RTS + pl;
-    if (qq < npix && ch0 + c4 < C) {
+    if (qq < npix && c4 < C) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
       const size_t o = (size_t)n * npix + (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68)
-      const float *ts = &sS[(g * RTS + pl) * TLD + c4];
-      const short *ta = &sA[(g * RTS + pl) * TLD + c4];
-      float *so = seg + o * C + ch0 + c4;
-      if (ch0 + c4 + 3 < C && (C & 3) == 0) {
-        *reinterpret_cast<float4 *>(so) = make_float4(ts[0], ts[1], ts[2], ts[3]);
+      float *so = seg + o * C + c4;
+      if (c4 + 3 < C && (C & 3) == 0) {
+        *reinterpret_cast<float4 *>(so) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         for (int t = 0; t < 4; ++t)
-          if (ch0 + c4 + t < C) so[t] = ts[t];
+          if (c4 + t < C) so[t] = v[t];
       }
       short4 o4;
-      o4.x = ta[0]; o4.y = ta[1]; o4.z = ta[2]; o4.w = ta[3];
-      *reinterpret_cast<short4 *>(arg + o * 32 + ch0 + c4) = o4;
+      o4.x = a[0]; o4.y = a[1]; o4.z = a[2]; o4.w = a[3];
+      *reinterpret_cast<short4 *>(arg + o * 32 + c4) = o4;
     }
   }
 }
