@@ -338,10 +338,20 @@ __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sq
 constexpr int NG = 4;            // waves per 64-pixel group, each walking a contiguous range of parts (8: 55.7 us, 4: 48 us)
 constexpr int SLD = 33;          // score tile row stride (floats per pixel: 32 channels + 1, conflict-free by lane)
 constexpr int ALD = 34;          // arg tile row stride (shorts per pixel: 17 dwords)
-constexpr int RTS = 1024 / NG;   // pixels per segmentation raster block (block = 1024 threads)
+#ifndef SMPLR_RASTER_BT
+#define SMPLR_RASTER_BT 1024
+#endif
+constexpr int RTS = SMPLR_RASTER_BT / NG;   // pixels per segmentation raster block
 constexpr int WPT = RTS / 64;    // 64-pixel sub-tiles per block
 constexpr int PART_COST = 4;     // fixed cost of a part in the balance, in records (exp, sqrt, winner re-scan)
-constexpr int NREC = 1024;  // records of a mesh's global list that fit the block's LDS copy (16 KB)
+constexpr int NREC = 1024;      // records of a mesh's global list that fit the block's LDS copy (per field)
+// LDS arena of a block, in floats: u[NREC] | v[NREC] | m^2[NREC] | tables of (v - row)^2, one row of the table per
+// image row the block touches; with unit weights the tables start over m^2 (never read then)
+#ifdef SMPLR_NO_TBL
+constexpr int ARENA = 3 * NREC;
+#else
+constexpr int ARENA = (SMPLR_RASTER_BT >= 1024) ? 7232 : 6912;
+#endif
 
 // One vertex against this lane's pixel: strict '<' keeps the first arg-min in list order.
 #define SMPLR_PAIR(rec, slot)                                   \
@@ -420,6 +430,58 @@ __device__ __forceinline__ void lds_scan(const char *base, int beg, int end, f32
   }
 }
 
+// The same scan with (v - row)^2 read from the block's row table instead of being recomputed per pixel:
+// rowoff = byte offset of this lane's image row in the table.  Keys are bit-identical to pair_key2's
+// (the table entry IS its t = dv * dv).
+template <bool UNIT>
+__device__ __forceinline__ void tbl_keys(const char *base, unsigned av, unsigned tv, f32x2 fc2, f32x2 &k01, f32x2 &k23) {
+  const f32x4 u = SMPLR_LDS_GROUP(av, 0);
+  const f32x4 t = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(base + tv, 16));
+  const f32x2 du01 = u.xy - fc2, du23 = u.zw - fc2;
+  k01 = __builtin_elementwise_fma(du01, du01, t.xy);
+  k23 = __builtin_elementwise_fma(du23, du23, t.zw);
+  if (!UNIT) {
+    const f32x4 m = SMPLR_LDS_GROUP(av, 2);
+    k01 = k01 * m.xy;
+    k23 = k23 * m.zw;
+  }
+}
+// Two groups per step (one address update each for the record and the table pointer); the running minimum is
+// carried through v_min3 and a group is the new winner iff it lowered it (strict, so the first minimal group in
+// list order wins, as in lds_scan).  The id kept for the first group of a step is its record offset av, for the
+// second the step's table pointer tv (>= TBL_ID, no extra register or instruction): tbl_group() decodes both.
+template <bool UNIT>
+__device__ __forceinline__ void lds_scan_tbl(const char *base, int beg, int end, unsigned rowoff, f32x2 fc2,
+                                             float &best, unsigned &bav) {
+  unsigned av = (unsigned)beg * 4u, tv = rowoff + (unsigned)beg * 4u;
+  asm volatile("" : "+v"(av));
+  asm volatile("" : "+v"(tv));
+  int k = beg;
+  for (; k + 2 * GP <= end; k += 2 * GP) {
+    f32x2 a01, a23, b01, b23;
+    tbl_keys<UNIT>(base, av, tv, fc2, a01, a23);
+    tbl_keys<UNIT>(base, av + GP * 4, tv + GP * 4, fc2, b01, b23);
+    const float na = fminf(fminf(a01.x, a01.y), fminf(fminf(a23.x, a23.y), best));
+    bav = na < best ? av : bav;
+    const float nb = fminf(fminf(b01.x, b01.y), fminf(fminf(b23.x, b23.y), na));
+    bav = nb < na ? tv : bav;
+    best = nb;
+    av += 2 * GP * 4;
+    tv += 2 * GP * 4;
+  }
+  if (k < end) {
+    f32x2 a01, a23;
+    tbl_keys<UNIT>(base, av, tv, fc2, a01, a23);
+    const float na = fminf(fminf(a01.x, a01.y), fminf(fminf(a23.x, a23.y), best));
+    bav = na < best ? av : bav;
+    best = na;
+  }
+}
+// record offset (bytes) of the winning group from the id lds_scan_tbl kept
+__device__ __forceinline__ unsigned tbl_group(unsigned id, unsigned rowoff) {
+  return id >= NREC * 4u ? id - rowoff + GP * 4u : id;
+}
+
 // Sum over each aligned group of 8 lanes, the same bits in all 8 (fixed tree: lane^1, lane^2, other quad).
 __device__ __forceinline__ float sum8_dpp(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
@@ -445,7 +507,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
                                                              unsigned wmagic) {
   __shared__ float sS[RTS * SLD];
   __shared__ short sA[RTS * ALD];
-  __shared__ f32x4 sRec[3 * NREC / 4];   // records, field-major: u[NREC] | v[NREC] | m^2[NREC]
+  __shared__ f32x4 sRec[ARENA / 4];      // records, field-major: u[NREC] | v[NREC] | m^2[NREC]; row tables
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
   const int bid = blockIdx.x;
@@ -468,7 +530,18 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   const int C = P + 1;
   // everything the block needs from global memory is requested up front (one round trip): the
   // pixel's local-record range, the list length, the unit-weight flag, the part offsets (-> LDS)
-  const int l0 = lstart[(size_t)n * (npix + 1) + qc], l1 = lstart[(size_t)n * (npix + 1) + qc + 1];
+  // (for the merge and write-out phase a pixel belongs to 8 adjacent lanes: item e = it * threads + tid is pixel
+  // e / 8 of the tile, channels 4 (e % 8) ...)
+  constexpr int NIT = 8 / NG;
+  const int sub = tid & 7;
+  int l0a[NIT], l1a[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int qq = tile * RTS + ((it * (RTS * NG) + tid) >> 3);
+    const int *lp = lstart + (size_t)n * (npix + 1) + (qq < npix ? qq : npix - 1);
+    l0a[it] = lp[0];
+    l1a[it] = qq < npix ? lp[1] : 0;                     // pixels past the image merge nothing
+  }
   const uint2 *lrecn = lrec + (size_t)n * K;
   const int lbase = goffn[P];
   const bool unit_m = goffn[P + 1] == 0;                 // every far-reaching weight is 1 (block-uniform)
@@ -478,20 +551,47 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   // array per field, and read by its 16 waves four records at a time with broadcast ds_read_b128
   // (in-order, counted waits); longer lists use the scalar-load path below.  Both evaluate the
   // same fp32 expressions.
-  static_assert(RTS * NG == NREC, "one record per thread");
-  {
+  float *const frec = reinterpret_cast<float *>(sRec);
+#pragma unroll
+  for (int i = tid; i < NREC; i += RTS * NG) {
     // thread i copies record i before the list length is even known (slots beyond it hold stale
     // bytes nobody reads), so the copy shares the first round trip to memory
-    const float4 t = Gn[min(tid, S - 1)];
-    float *f = reinterpret_cast<float *>(sRec);
-    f[tid] = t.x;
-    f[NREC + tid] = t.y;
-    f[2 * NREC + tid] = t.z;
+    const float4 t = Gn[min(i, S - 1)];
+    frec[i] = t.x;
+    frec[NREC + i] = t.y;
+    frec[2 * NREC + i] = t.z;
   }
   const bool in_lds = lbase <= NREC;                     // block-uniform
+  // (v - row)^2 of every record for the image rows this block touches (6 at W = 48), so that a pair costs
+  // a subtract and an fma instead of two subtracts, a multiply and an fma; used when the tables fit
+  const int row0 = (int)(((unsigned)min(tile * RTS, npix - 1) * wmagic) >> 24);
+  const int nrows = (int)(((unsigned)min(tile * RTS + RTS - 1, npix - 1) * wmagic) >> 24) - row0 + 1;
+  // table row stride: consecutive rows (the most a 16-lane read group spans) must not share banks
+  const int lb4 = (lbase + 3) & ~3;
+  const int RS = ((lb4 & 63) >= 4 && (lb4 & 63) <= 60) ? lb4 : lb4 + 4;
+  const int toff = unit_m ? 2 * NREC : 3 * NREC;
+#ifdef SMPLR_NO_TBL
+  const bool tbl = false;
+#else
+  const bool tbl = in_lds && nrows * RS <= ARENA - toff;  // block-uniform
+#endif
   __syncthreads();
-  // the first two local records of this pixel are fetched now and used after the pair loop
-  const uint2 lr0 = lrecn[min(l0, K - 1)], lr1 = lrecn[min(l0 + 1, K - 1)];
+  if (tbl) {
+    const int n4 = (lbase + 3) >> 2;
+    for (int e = tid; e < nrows * n4; e += RTS * NG) {
+      const int j = e / n4, k4 = e - j * n4;
+      const f32x4 v = sRec[NREC / 4 + k4];
+      const float frj = (float)(row0 + j);
+      const f32x4 dv = v - frj;
+      *reinterpret_cast<f32x4 *>(frec + toff + j * RS + 4 * k4) = dv * dv;
+    }
+    __syncthreads();
+  }
+  const unsigned rowoff = (unsigned)(toff + (r - row0) * RS) * 4u;
+  // the first 8 local records of each of this lane's merge pixels are fetched now and used after the pair loop
+  uint2 lr0[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) lr0[it] = lrecn[min(l0a[it] + sub, K - 1)];
   const f32x2 fc2 = {fc, fc}, fr2 = {fr, fr};
   float *myS = &sS[pt * SLD + 1];                        // indexed by part (channel = part + 1)
   short *myA = &sA[pt * ALD + 1];
@@ -521,11 +621,19 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
         if (beg < end) {
           unsigned bav = 0xffffffffu;
           const char *base = reinterpret_cast<const char *>(sRec);
-          if (unit_m) lds_scan<true>(base, beg, end, fc2, fr2, best, bav);
-          else lds_scan<false>(base, beg, end, fc2, fr2, best, bav);
+          if (tbl) {
+            if (unit_m) lds_scan_tbl<true>(base, beg, end, rowoff, fc2, best, bav);
+            else lds_scan_tbl<false>(base, beg, end, rowoff, fc2, best, bav);
+            if (bav != 0xffffffffu) bav = tbl_group(bav, rowoff);
+          } else {
+            if (unit_m) lds_scan<true>(base, beg, end, fc2, fr2, best, bav);
+            else lds_scan<false>(base, beg, end, fc2, fr2, best, bav);
+          }
           // the winning group is looked at once more for the first record that attains the minimum
           if (bav != 0xffffffffu) {
-            const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1), m = SMPLR_LDS_GROUP(bav, 2);
+            const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1);
+            f32x4 m = {1.f, 1.f, 1.f, 1.f};                // x * 1 = x: the unit-weight scan's keys exactly
+            if (!unit_m) m = SMPLR_LDS_GROUP(bav, 2);
             const f32x2 k01 = pair_key2<false>(u.xy, v.xy, m.xy, fc2, fr2);
             const f32x2 k23 = pair_key2<false>(u.zw, v.zw, m.zw, fc2, fr2);
             bslot = (int)(bav >> 2) + ((k01.x == best) ? 0 : (k01.y == best) ? 1 : (k23.x == best) ? 2 : 3);
@@ -555,25 +663,37 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       beg = end;
     }
   }
-  // merge this pixel's local records (invisible vertices that round to this pixel)
-  for (int i = l0; i < l1; ++i) {
-    const uint2 rec = (i == l0) ? lr0 : (i == l0 + 1) ? lr1 : lrecn[i];
-    const int p = (int)rec.y;
-    if (p >= ps && p < pe) {
-      const float sc = fast_exp_neg(__uint_as_float(rec.x));
-      if (sc > myS[p]) {                                   // ties keep the earlier (global) winner
-        myS[p] = sc;
-        myA[p] = (short)(lbase + i);
-      }
-    }
-  }
   __syncthreads();
-  // all 16 waves write the tile: 8 lanes per pixel, 4 channels each (coalesced 128-B / 64-B pixel rows)
-  constexpr int NIT = 8 / NG;
+  // The tile now holds every part's best visible vertex.  All 16 waves merge the local records (invisible
+  // vertices that round to the pixel) and write the tile out: 8 lanes per pixel, each taking every 8th record
+  // of the pixel's list, then 4 channels of its row (coalesced 128-B / 64-B pixel rows).  A record replaces the
+  // tile's score only if strictly larger (ties keep the earlier winner, global before local): an LDS atomic max
+  // on the score bits (scores are >= 0, so the integer order is the float order) whose return value tells the
+  // lane whether it raised the slot; the slot read back tells it whether a later lane of the same step raised
+  // it further.  LDS operations of one wave execute in order, so no barrier separates merge and write-out.
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = it * (RTS * NG) + tid;
     const int pl = e >> 3, c4 = (e & 7) * 4;
+    {
+      int *rowS = reinterpret_cast<int *>(&sS[pl * SLD + 1]);
+      short *rowA = &sA[pl * ALD + 1];
+      const int l1 = l1a[it];
+      int i = l0a[it] + sub;
+      uint2 rec = lr0[it];
+      while (__any(i < l1)) {
+        const uint2 nxt = lrecn[min(i + 8, K - 1)];        // next step's record, in flight during this one
+        if (i < l1) {
+          const int sc = __float_as_int(fast_exp_neg(__uint_as_float(rec.x)));
+          const int p = (int)rec.y;
+          const int old = atomicMax(&rowS[p], sc);
+          const int fin = *reinterpret_cast<volatile int *>(&rowS[p]);
+          if (old < sc && fin == sc) rowA[p] = (short)(lbase + i);
+        }
+        rec = nxt;
+        i += 8;
+      }
+    }
     const float *ts = &sS[pl * SLD + c4];
     const short *ta = &sA[pl * ALD + c4];
     float v[4];
