@@ -610,11 +610,12 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   }
 
   {
-    int beg = __builtin_amdgcn_readfirstlane(sOff[ps]);
-    int nxt = __builtin_amdgcn_readfirstlane(sOff[(ps + 1) < P ? (ps + 1) : P]);   // end of the current part
+    // the part offsets sit in a VGPR, one per lane (P + 1 <= 32), and a part's range is a v_readlane away
+    // instead of an LDS round trip per part
+    const int offv = sOff[lane <= P ? lane : P];
+    int beg = __builtin_amdgcn_readlane(offv, ps);
     for (int p = ps; p < pe; ++p) {
-      const int end = nxt;
-      nxt = __builtin_amdgcn_readfirstlane(sOff[(p + 2) < P ? (p + 2) : P]);   // the next part's end
+      const int end = __builtin_amdgcn_readlane(offv, p + 1);
       float best = INFINITY;
       int bslot = -1;
       if (in_lds) {
@@ -631,12 +632,19 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
           }
           // the winning group is looked at once more for the first record that attains the minimum
           if (bav != 0xffffffffu) {
-            const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1);
-            f32x4 m = {1.f, 1.f, 1.f, 1.f};                // x * 1 = x: the unit-weight scan's keys exactly
-            if (!unit_m) m = SMPLR_LDS_GROUP(bav, 2);
-            const f32x2 k01 = pair_key2<false>(u.xy, v.xy, m.xy, fc2, fr2);
-            const f32x2 k23 = pair_key2<false>(u.zw, v.zw, m.zw, fc2, fr2);
-            bslot = (int)(bav >> 2) + ((k01.x == best) ? 0 : (k01.y == best) ? 1 : (k23.x == best) ? 2 : 3);
+            f32x2 k01, k23;
+            if (tbl) {
+              if (unit_m) tbl_keys<true>(base, bav, rowoff + bav, fc2, k01, k23);
+              else tbl_keys<false>(base, bav, rowoff + bav, fc2, k01, k23);
+            } else {
+              const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1);
+              f32x4 m = {1.f, 1.f, 1.f, 1.f};              // x * 1 = x: the unit-weight scan's keys exactly
+              if (!unit_m) m = SMPLR_LDS_GROUP(bav, 2);
+              k01 = pair_key2<false>(u.xy, v.xy, m.xy, fc2, fr2);
+              k23 = pair_key2<false>(u.zw, v.zw, m.zw, fc2, fr2);
+            }
+            const int w23 = (k23.x == best) ? 2 : 3, w13 = (k01.y == best) ? 1 : w23;
+            bslot = (int)(bav >> 2) + ((k01.x == best) ? 0 : w13);
           }
         }
       } else if (beg < end) {
