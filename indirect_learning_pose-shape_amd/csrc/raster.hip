@@ -343,7 +343,7 @@ constexpr int ALD = 34;          // arg tile row stride (shorts per pixel: 17 dw
 #endif
 constexpr int RTS = SMPLR_RASTER_BT / NG;   // pixels per segmentation raster block
 constexpr int WPT = RTS / 64;    // 64-pixel sub-tiles per block
-constexpr int PART_COST = 4;     // fixed cost of a part in the balance, in records (exp, sqrt, winner re-scan)
+constexpr int PART_COST = 16;    // fixed cost of a part in the balance, in records (exp, sqrt, winner re-scan; 4: +0.4 us)
 constexpr int NREC = 1024;      // records of a mesh's global list that fit the block's LDS copy (per field)
 // LDS arena of a block, in floats: u[NREC] | v[NREC] | m^2[NREC] | tables of (v - row)^2, one row of the table per
 // image row the block touches; with unit weights the tables start over m^2 (never read then)
