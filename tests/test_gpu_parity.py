@@ -517,6 +517,35 @@ def test_seg_generic_masks_and_odd_width(layer, part_tables, mask_kind):
     grad_close(pg.grad.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(seg, %s mask, W=50)" % mask_kind)
 
 
+@pytest.mark.parametrize("W,nfar,unit", [(48, 300, True), (48, 300, False), (48, 780, False), (48, 950, True),
+                                         (48, 1100, True), (32, 300, True), (32, 700, True), (64, 600, False),
+                                         (96, 500, True)])
+def test_seg_record_list_regimes(layer, part_tables, W, nfar, unit):
+    """The forward rasteriser picks its pair loop by the length of a mesh's far-reaching record list and by the
+    weights: (v - row)^2 row tables in LDS (lists up to ~860 records at W = 48 with unit weights, ~690 otherwise,
+    fewer when a tile touches more image rows: W = 32), the plain LDS copy up to 1 024, scalar loads beyond.  A
+    mask with exactly `nfar` far-reaching vertices (weight 1, or mixed weights below the reach threshold) pins
+    each regime; every one must match the float64 oracle, scores and arg-min."""
+    from ilps_amd.keras_smpl.projects_to_seg import projects_to_seg
+    from oracle import np_oracle as o
+    _, _, proj = _decoder_inputs(layer, 2, W, 57 + nfar)
+    proj = proj.detach()
+    rng = np.random.default_rng(nfar + W)
+    m = np.full((2, 6890), 500.0)
+    for b in range(2):
+        idx = rng.choice(6890, size=nfar, replace=False)
+        m[b, idx] = 1.0 if unit else rng.choice([0.5, 1.0, 3.0, 150.0], size=nfar)
+    mask = t(m)
+    seg, arg = projects_to_seg([proj, mask], W, return_argmin=True)
+    ids, off = part_tables[1]
+    want, warg = o.projects_to_seg(proj.cpu().numpy().astype(np.float64), m, W, ids, off, return_argmin=True)
+    got = seg.cpu().numpy()
+    assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
+    a = arg.cpu().numpy().astype(np.int64)
+    agree = (a == warg) | (want[..., 1:] < 1e-30)
+    assert agree.mean() > 0.999
+
+
 def test_silhouette_odd_width_and_outliers(layer):
     """W = 50 and vertices far outside the cell window (outlier list) in the pruned silhouette."""
     from ilps_amd.keras_smpl.projects_to_silhouette import projects_to_silhouette
