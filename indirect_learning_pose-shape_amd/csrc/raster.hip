@@ -482,6 +482,34 @@ __device__ __forceinline__ unsigned tbl_group(unsigned id, unsigned rowoff) {
   return id >= NREC * 4u ? id - rowoff + GP * 4u : id;
 }
 
+// A wave's parts [ps, pe) in table mode, specialised by the weights so that no mode is tested per part; offv =
+// the part offsets, one per lane.  A non-empty part always has a finite key (its pads come after real records),
+// so the winner re-scan is unconditional and only the final selects look at best < inf.
+template <bool UNIT>
+__device__ __forceinline__ void scan_parts_tbl(const char *base, int offv, int ps, int pe, unsigned rowoff,
+                                               f32x2 fc2, float *myS, short *myA) {
+  int beg = __builtin_amdgcn_readlane(offv, ps);
+  for (int p = ps; p < pe; ++p) {
+    const int end = __builtin_amdgcn_readlane(offv, p + 1);
+    float best = INFINITY;
+    int bslot = -1;
+    if (beg < end) {
+      unsigned bav = 0xffffffffu;
+      lds_scan_tbl<UNIT>(base, beg, end, rowoff, fc2, best, bav);
+      // the winning group is looked at once more for the first record that attains the minimum
+      const unsigned wav = (bav == 0xffffffffu) ? (unsigned)beg * 4u : tbl_group(bav, rowoff);
+      f32x2 k01, k23;
+      tbl_keys<UNIT>(base, wav, rowoff + wav, fc2, k01, k23);
+      const int w23 = (k23.x == best) ? 2 : 3, w13 = (k01.y == best) ? 1 : w23;
+      const int w = (int)(wav >> 2) + ((k01.x == best) ? 0 : w13);
+      bslot = (best < INFINITY) ? w : -1;
+    }
+    myS[p] = (best < INFINITY) ? fast_exp_neg(fast_sqrt(best)) : 0.0f;
+    myA[p] = (short)bslot;
+    beg = end;
+  }
+}
+
 // Sum over each aligned group of 8 lanes, the same bits in all 8 (fixed tree: lane^1, lane^2, other quad).
 __device__ __forceinline__ float sum8_dpp(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
@@ -613,6 +641,12 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     // the part offsets sit in a VGPR, one per lane (P + 1 <= 32), and a part's range is a v_readlane away
     // instead of an LDS round trip per part
     const int offv = sOff[lane <= P ? lane : P];
+    const char *base = reinterpret_cast<const char *>(sRec);
+    if (tbl) {                                             // block-uniform: the standard case
+      if (unit_m) scan_parts_tbl<true>(base, offv, ps, pe, rowoff, fc2, myS, myA);
+      else scan_parts_tbl<false>(base, offv, ps, pe, rowoff, fc2, myS, myA);
+      pe = ps;                                             // nothing left for the generic loop
+    }
     int beg = __builtin_amdgcn_readlane(offv, ps);
     for (int p = ps; p < pe; ++p) {
       const int end = __builtin_amdgcn_readlane(offv, p + 1);
@@ -621,28 +655,15 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       if (in_lds) {
         if (beg < end) {
           unsigned bav = 0xffffffffu;
-          const char *base = reinterpret_cast<const char *>(sRec);
-          if (tbl) {
-            if (unit_m) lds_scan_tbl<true>(base, beg, end, rowoff, fc2, best, bav);
-            else lds_scan_tbl<false>(base, beg, end, rowoff, fc2, best, bav);
-            if (bav != 0xffffffffu) bav = tbl_group(bav, rowoff);
-          } else {
-            if (unit_m) lds_scan<true>(base, beg, end, fc2, fr2, best, bav);
-            else lds_scan<false>(base, beg, end, fc2, fr2, best, bav);
-          }
+          if (unit_m) lds_scan<true>(base, beg, end, fc2, fr2, best, bav);
+          else lds_scan<false>(base, beg, end, fc2, fr2, best, bav);
           // the winning group is looked at once more for the first record that attains the minimum
           if (bav != 0xffffffffu) {
-            f32x2 k01, k23;
-            if (tbl) {
-              if (unit_m) tbl_keys<true>(base, bav, rowoff + bav, fc2, k01, k23);
-              else tbl_keys<false>(base, bav, rowoff + bav, fc2, k01, k23);
-            } else {
-              const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1);
-              f32x4 m = {1.f, 1.f, 1.f, 1.f};              // x * 1 = x: the unit-weight scan's keys exactly
-              if (!unit_m) m = SMPLR_LDS_GROUP(bav, 2);
-              k01 = pair_key2<false>(u.xy, v.xy, m.xy, fc2, fr2);
-              k23 = pair_key2<false>(u.zw, v.zw, m.zw, fc2, fr2);
-            }
+            const f32x4 u = SMPLR_LDS_GROUP(bav, 0), v = SMPLR_LDS_GROUP(bav, 1);
+            f32x4 m = {1.f, 1.f, 1.f, 1.f};                // x * 1 = x: the unit-weight scan's keys exactly
+            if (!unit_m) m = SMPLR_LDS_GROUP(bav, 2);
+            const f32x2 k01 = pair_key2<false>(u.xy, v.xy, m.xy, fc2, fr2);
+            const f32x2 k23 = pair_key2<false>(u.zw, v.zw, m.zw, fc2, fr2);
             const int w23 = (k23.x == best) ? 2 : 3, w13 = (k01.y == best) ? 1 : w23;
             bslot = (int)(bav >> 2) + ((k01.x == best) ? 0 : w13);
           }
