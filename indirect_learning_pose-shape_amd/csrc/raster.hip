@@ -605,13 +605,15 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
 #endif
   __syncthreads();
   if (tbl) {
-    const int n4 = (lbase + 3) >> 2;
-    for (int e = tid; e < nrows * n4; e += RTS * NG) {
-      const int j = e / n4, k4 = e - j * n4;
+    // thread -> (group of 4 records k4 = tid % 256, rows tid / 256, + 4, ...): lbase <= NREC = 1 024 records
+    const int n4 = (lbase + 3) >> 2, k4 = tid & 255;
+    if (k4 < n4) {
       const f32x4 v = sRec[NREC / 4 + k4];
-      const float frj = (float)(row0 + j);
-      const f32x4 dv = v - frj;
-      *reinterpret_cast<f32x4 *>(frec + toff + j * RS + 4 * k4) = dv * dv;
+      for (int j = tid >> 8; j < nrows; j += (RTS * NG) >> 8) {
+        const float frj = (float)(row0 + j);
+        const f32x4 dv = v - frj;
+        *reinterpret_cast<f32x4 *>(frec + toff + j * RS + 4 * k4) = dv * dv;
+      }
     }
     __syncthreads();
   }
