@@ -165,7 +165,8 @@ int smplr_visibility(const float *proj, int B, int VP, int grid_wh, int ref_comp
 
 /* ---- projects_to_seg: keras_smpl/projects_to_seg.py:9-69 -------------------------------- */
 /* Part table, built once on the host from part_vertices.pkl (projects_to_seg.py:18-24,36-37):
- *   part_pos (K) int32: positions into the VP-long vertex list, part-major (K = 6879);
+ *   part_pos (K) int32: positions into the VP-long vertex list, part-major (K = 6879); every position at most
+ *     once (the reference's tables are partitions; the backward keeps one record slot per vertex);
  *   part_off (P+1) int32: CSR offsets of the P parts.
  * mask values must be >= 0 (the reference produces {1, 500}).
  * workspace: smplr_seg_workspace(B,VP,W,P,K) bytes of scratch.

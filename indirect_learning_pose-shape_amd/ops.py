@@ -128,6 +128,11 @@ def build_part_table(ids, off, vertex_sampling, num_verts, device) -> PartTable:
     part_pos = (np.asarray(ids, np.int64) // vs).astype(np.int32)          # :36-37
     VP = (num_verts + vs - 1) // vs
     assert part_pos.min() >= 0 and part_pos.max() < VP and int(off[-1]) == len(part_pos)
+    if len(np.unique(part_pos)) != len(part_pos):
+        # the backward keeps ONE record slot per vertex (plain stores / gather by vertex, no atomics); the
+        # reference's three tables (part_vertices.pkl, 2_/5_sampled_part_vertices.pkl) are partitions
+        raise ValueError("part table lists a vertex position more than once (after // vertex_sampling): "
+                         "each vertex may belong to at most one part")
     return PartTable(P=P, K=int(len(part_pos)),
                      part_pos=torch.as_tensor(part_pos).to(device),
                      part_off=torch.as_tensor(np.asarray(off, np.int32)).to(device), VP=VP)

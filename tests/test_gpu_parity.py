@@ -546,6 +546,36 @@ def test_seg_record_list_regimes(layer, part_tables, W, nfar, unit):
     assert agree.mean() > 0.999
 
 
+@pytest.mark.parametrize("P,VP,W,B", [(1, 64, 24, 3), (5, 300, 40, 9), (17, 1000, 48, 2), (31, 500, 20, 11)])
+def test_seg_custom_part_tables(P, VP, W, B):
+    """The C ABI takes any part table (P <= 31 parts, each vertex in at most one part, some in none)
+    and any vertex count: fewer than 32 output channels, fewer records than a wave's group, batch sizes that do
+    not fill the 8-XCD workgroup map, images smaller than one 256-pixel tile.  Forward against the float64
+    oracle, backward against autograd through the float64 torch oracle."""
+    from ilps_amd import ops
+    from oracle import np_oracle as o
+    from oracle import torch_oracle as to
+    rng = np.random.default_rng(100 * P + W)
+    perm = rng.permutation(VP)                      # a vertex belongs to at most one part (some to none)
+    cuts = np.sort(rng.choice(np.arange(1, VP - VP // 8), size=P, replace=False))
+    off = [0] + [int(c) for c in cuts]
+    ids = [int(v) for v in perm[:off[-1]]]
+    pt = ops.build_part_table(ids, off, None, VP, dev())
+    proj_np = np.concatenate([rng.uniform(-4.0, W + 4.0, (B, VP, 2)), rng.normal(0, 1, (B, VP, 1))], axis=2)
+    m = rng.choice([1.0, 500.0], size=(B, VP), p=[0.3, 0.7])
+    proj, mask = t(proj_np), t(m)
+    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt)[:3]
+    want = o.projects_to_seg(proj.cpu().numpy().astype(np.float64), m, W, ids, off)
+    got = seg.cpu().numpy()
+    assert got.shape == (B, W, W, P + 1)
+    assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
+    g = rng.normal(0, 1, got.shape)
+    dproj = ops._seg_bwd(t(g), arg, rec, VP, W, pt)
+    po = torch.tensor(proj.cpu().numpy(), dtype=torch.float64, requires_grad=True)
+    (to.projects_to_seg(po, torch.tensor(m), W, ids, off) * torch.tensor(g)).sum().backward()
+    grad_close(dproj.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(custom table P=%d)" % P)
+
+
 def test_silhouette_odd_width_and_outliers(layer):
     """W = 50 and vertices far outside the cell window (outlier list) in the pruned silhouette."""
     from ilps_amd.keras_smpl.projects_to_silhouette import projects_to_silhouette

@@ -172,3 +172,16 @@ def test_part_tables_match_the_reference_coloured_template():
         ids_s, off_s = load_part_tables(vs)
         for p in range(31):
             assert np.all(part[ids_s[off_s[p]:off_s[p + 1]]] == p)
+
+
+def test_part_table_rejects_repeated_vertices():
+    """One record slot per vertex in the backward: a table that lists a position twice (directly, or after the
+    division by vertex_sampling) is refused up front instead of producing a wrong gradient."""
+    import torch
+    from ilps_amd import ops
+    ok = ops.build_part_table([0, 2, 4, 6, 8], [0, 2, 5], 2, 10, torch.device("cpu"))
+    assert ok.P == 2 and ok.K == 5 and ok.VP == 5
+    with pytest.raises(ValueError):
+        ops.build_part_table([0, 1, 2, 1], [0, 2, 4], None, 10, torch.device("cpu"))
+    with pytest.raises(ValueError):
+        ops.build_part_table([0, 1, 4], [0, 1, 3], 2, 10, torch.device("cpu"))      # 0 // 2 == 1 // 2
