@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
                                                         short *__restrict__ vslot) {
   // (16-B aligned: the 64-bit z-buffer keys behind the counters need 8, whatever the static LDS in front)
   extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // npix | VIS: z-buffer keys, visible flags | STAGE: u[VP], v[VP]
-  __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64];
+  __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64], s_gb[BIN_T];
   __shared__ int s_any_empty, s_nonunit;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int npix = W * W;
@@ -215,6 +215,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   // passes), count
   Slot sl[IPT_MAX];
   int gcnt = 0;
+  unsigned gbits = 0;                            // bit j: this thread's slot j is a global record
 #pragma unroll
   for (int j = 0; j < IPT_MAX; ++j) {
     const int k = k0 + j;
@@ -227,22 +228,35 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
     if (sl[j].cls == 1) {
       ++gcnt;
+      gbits |= 1u << j;
       if (sl[j].m != 1.0f) s_nonunit = 1;     // benign same-value race; read after the scans' barriers
     } else if (sl[j].cls == 2) {
       atomicAdd(&s_cnt[sl[j].pix], 1);
     }
   }
-  int gtotal;
-  const int gbase = block_excl_scan(gcnt, s_wave, &gtotal);
-  if (tid <= P) s_gstart[tid] = gtotal;   // default for empty trailing parts; ordered by the scan's barriers
-  // counting sort offsets over pixels
+  // the part of this thread's first slot (largest p with poff[p] <= k0), for the placement
+  int p0 = 0;
+  if (k0 < k1) {
+    int lo = 0, hi = P;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_poff[mid] <= k0) lo = mid; else hi = mid;
+    }
+    p0 = lo;
+  }
+  __syncthreads();                               // pixel counters complete
+  // ONE block scan for both prefixes: global records per thread (low half) and local records per thread's
+  // pixel range (high half); K <= 8192 keeps either total below 2^16
+  const int ept = (npix + BIN_T - 1) / BIN_T;
+  const int e0 = tid * ept, e1 = min(npix, e0 + ept);
+  int loc = 0;
+  for (int e = e0; e < e1; ++e) loc += s_cnt[e];
+  int tot2;
+  const int base2 = block_excl_scan(gcnt | (loc << 16), s_wave, &tot2);
+  const int gbase = base2 & 0xffff, gtotal = tot2 & 0xffff, ltotal = tot2 >> 16;
+  s_gb[tid] = gbase | (int)(gbits << 16);
   {
-    const int ept = (npix + BIN_T - 1) / BIN_T;
-    const int e0 = tid * ept, e1 = min(npix, e0 + ept);
-    int loc = 0;
-    for (int e = e0; e < e1; ++e) loc += s_cnt[e];
-    int ltotal;
-    int run = block_excl_scan(loc, s_wave, &ltotal);
+    int run = base2 >> 16;                       // counting sort offsets over pixels
     for (int e = e0; e < e1; ++e) {
       const int c = s_cnt[e];
       s_cnt[e] = run;            // becomes the placement cursor
@@ -251,31 +265,19 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
     if (tid == 0) lstartn[npix] = ltotal;
   }
-  // pass 2: global prefix at part starts
-  int p0 = 0;
-  if (k0 < k1) {
-    int lo = 0, hi = P;        // largest p with poff[p] <= k0
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (s_poff[mid] <= k0) lo = mid; else hi = mid;
-    }
-    p0 = lo;
-  }
-  {
-    int p = p0, run = gbase;
-#pragma unroll
-    for (int j = 0; j < IPT_MAX; ++j) {
-      const int k = k0 + j;
-      if (j < ipt && k < k1) {
-        while (k >= s_poff[p + 1]) ++p;
-        for (int pp = p; pp >= 0 && s_poff[pp] == k; --pp) s_gstart[pp] = run;   // (also empty parts)
-        if (sl[j].cls == 1) ++run;
-      }
-    }
-  }
   __syncthreads();
-  if (tid < 64) {                              // padded part offsets: one wave scan (P <= 31)
-    const int cnt = (tid < P) ? (s_gstart[tid + 1] - s_gstart[tid] + GP - 1) / GP * GP : 0;
+  if (tid < 64) {
+    // global prefix at each part's first slot: the owning thread's base + its global flags below that slot
+    // (empty parts share a slot; parts that start at K take the total); then the padded part offsets (P <= 31)
+    int gs = gtotal;
+    const int kk = s_poff[tid <= P ? tid : P];
+    if (tid < P && kk < K) {
+      const int t = kk / ipt, j = kk - t * ipt;
+      const int w = s_gb[t];
+      gs = (w & 0xffff) + __popc(((unsigned)w >> 16) & ((1u << j) - 1u));
+    }
+    const int gnext = __shfl_down(gs, 1, 64);
+    const int cnt = (tid < P) ? (gnext - gs + GP - 1) / GP * GP : 0;
     int inc = cnt;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) {
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       if (tid >= o) inc += t;
     }
     if (tid <= P) {
+      s_gstart[tid] = gs;
       s_gpad[tid] = inc - cnt;                 // tid == P: cnt = 0, inc = total
       goffn[tid] = inc - cnt;
     }
