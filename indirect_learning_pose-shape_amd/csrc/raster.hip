@@ -736,9 +736,18 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     short a[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const bool part_ch = c4 + t >= 1 && c4 + t < C;     // the tile holds nothing for channel 0 and slots >= C
-      v[t] = part_ch ? ts[t] : 0.0f;
-      a[t] = part_ch ? ta[t] : (short)-1;
+      v[t] = ts[t];
+      a[t] = ta[t];
+    }
+    if (c4 == 0) v[0] = 0.0f;                              // the tile holds nothing for channel 0 ...
+    if (C != 32) {                                         // ... nor for slots >= C (block-uniform: not the reference's 31 parts)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c4 + t >= C) {
+          v[t] = 0.0f;
+          a[t] = (short)-1;
+        }
+      }
     }
     const float sum = sum8_dpp((v[0] + v[1]) + (v[2] + v[3]));   // over the pixel's parts (all lanes take part)
     if (c4 == 0) {
@@ -748,8 +757,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     const int qq = tile * RTS + pl;
     if (qq < npix && c4 < C) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
-      const size_t o = (size_t)n * npix + (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68)
-      float *so = seg + o * C + c4;
+      const unsigned po = (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68); mesh base + 32-bit offset
+      float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
       if (c4 + 3 < C && (C & 3) == 0) {
         *reinterpret_cast<float4 *>(so) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -758,7 +767,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       }
       short4 o4;
       o4.x = a[0]; o4.y = a[1]; o4.z = a[2]; o4.w = a[3];
-      *reinterpret_cast<short4 *>(arg + o * 32 + c4) = o4;
+      *reinterpret_cast<short4 *>(arg + (size_t)n * npix * 32 + (po * 32u + (unsigned)c4)) = o4;
     }
   }
 }
