@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMPLR_ABI_VERSION 2
+#define SMPLR_ABI_VERSION 3
 #define SMPLR_NJ 24            /* joints                                   */
 #define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
 #define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
@@ -135,7 +135,8 @@ int smplr_skin_bwd(const float *dverts, const float *dproj,
  * The blend GEMM uses blend3_bwd (smplr_blend3_pack's pk_bwd) when it is not NULL, else blend_t.
  * seg_part / seg_vslot / seg_nsplit (NULL, NULL, 0 to omit): the segmentation rasteriser's gradient as
  * smplr_seg_bwd leaves it when called with dproj = NULL - per-row-block slot sums in its workspace - plus
- * the vertex -> slot map of the forward and smplr_seg_bwd_nsplit(W).  The skinning backward then gathers
+ * the vertex -> slot map of the forward and smplr_seg_bwd_nsplit(B,W) (row blocks per mesh: 8 image rows each,
+ * 24 once the batch still gives every CU a row block).  The skinning backward then gathers
  * d(seg)/d(proj) by vertex, summing the row blocks in the order the merge kernel would have (bit-identical),
  * and adds it to dproj (if given): one launch and one (B,VP,3) round trip less.
  * workspace: smplr_smpl_bwd_workspace(B,V) bytes.                                              */
@@ -201,9 +202,9 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:
  * NaN).  The score is recomputed from the arg-min record, so seg itself is not an input.
  * workspace: smplr_seg_bwd_workspace(B,W) bytes (per-row-block partial sums, merged in order).
- * dproj = NULL stops after the partial sums: the workspace (B, smplr_seg_bwd_nsplit(W), 5, 4096, 2) then IS
+ * dproj = NULL stops after the partial sums: the workspace (B, smplr_seg_bwd_nsplit(B,W), 5, 4096, 2) then IS
  * the result, to be handed to smplr_smpl_bwd together with the forward's vslot.                   */
-int smplr_seg_bwd_nsplit(int W);
+int smplr_seg_bwd_nsplit(int B, int W);
 size_t smplr_seg_bwd_workspace(int B, int W);
 int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
                   int B, int VP, int W, int P, int K, float *dproj, void *workspace, void *stream);

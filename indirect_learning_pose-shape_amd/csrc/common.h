@@ -55,10 +55,16 @@ int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B,
 int skin_bwd_nblk(int V);
 // The segmentation backward's per-row-block slot sums (raster.hip), which the skinning backward can gather
 // by vertex instead of reading a merged dproj: part (B, nsplit, SB_NWIN, SB_SLOTS, 2), vslot (B, VP) = the
-// record slot of each vertex (-1: none), nsplit = ceil(W / SB_ROWS).
+// record slot of each vertex (-1: none), nsplit = ceil(W / seg_bwd_rows(B, W)).
 constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators per window
 constexpr int SB_NWIN = 5;       // slot windows the partial buffer holds: S <= 20480
-constexpr int SB_ROWS = 8;       // rows (strips) per block
+constexpr int SB_ROWS = 8;       // rows (strips) per block at small batch ...
+constexpr int SB_ROWS_BIG = 24;  // ... and once that still leaves every CU a block: fewer zero / write-out passes
+                                 // over the accumulators and fewer partials per vertex for the gather
+                                 // (B = 128: seg_bwd -1.0 us, skin_bwd -0.4; at B = 32 it would cost 4 us)
+inline int seg_bwd_rows(int B, int W) {
+  return ((long long)B * ((W + SB_ROWS_BIG - 1) / SB_ROWS_BIG) >= 256) ? SB_ROWS_BIG : SB_ROWS;
+}
 struct SegGrad { const float *part; const int16_t *vslot; int nsplit; };
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,

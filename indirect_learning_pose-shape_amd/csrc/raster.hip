@@ -786,7 +786,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
 // global atomic).  A mesh with more than SB_SLOTS records (only when most vertices are marked
 // visible) is walked once per window of SB_SLOTS slots.  Run-to-run differences are confined to
 // the order in which a block's strips reach a slot's LDS accumulator (last-ulp rounding).
-// (SB_SLOTS = 4096 accumulators per window, SB_NWIN = 5 windows, SB_ROWS = 8 rows per block: common.h)
+// (SB_SLOTS = 4096 accumulators per window, SB_NWIN = 5 windows, 8 or 24 rows per block by batch size: common.h)
 constexpr int SB_U = 8;          // pixels in flight per lane
 
 __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float sy) {
@@ -873,13 +873,13 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
   seg_flush(acc, cur, sx, sy);
 }
 
-__global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ dseg,
+__global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *__restrict__ dseg,
                                                       const short *__restrict__ arg,
                                                       const float4 *__restrict__ rec, int S, int VP, int W,
                                                       int P, float *__restrict__ dproj,
-                                                      float *__restrict__ part) {
+                                                      float *__restrict__ part, int rows) {
   __shared__ float acc[SB_SLOTS * 2];
-  const int n = blockIdx.y, tid = threadIdx.x;
+  const int n = blockIdx.y, tid = threadIdx.x, nthr = 32 * rows;   // a 32-lane group per row of the block
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
   if (dproj) {                                                // (NULL: the consumer gathers the slot sums itself)
@@ -887,11 +887,11 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
     float *dp = dproj + (size_t)n * VP * 3;
     const int tot = VP * 3, per = (tot + gridDim.x - 1) / gridDim.x;
     const int z0 = blockIdx.x * per, z1 = min(tot, z0 + per);
-    for (int i = z0 + tid; i < z1; i += 256) dp[i] = 0.0f;
+    for (int i = z0 + tid; i < z1; i += nthr) dp[i] = 0.0f;
   }
   const int C = P + 1, npix = W * W;
   const int ch = tid & 31, strip = tid >> 5;
-  const int ro = blockIdx.x * SB_ROWS + strip;            // output (flipped) row of this strip
+  const int ro = blockIdx.x * rows + strip;            // output (flipped) row of this strip
   const float fr = (float)(W - 1 - ro);
   const size_t row0 = (size_t)n * npix + (size_t)ro * W;
   const int nwin = (nslots + SB_SLOTS - 1) / SB_SLOTS;    // 1 in the standard pipeline
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
     const int base = win * SB_SLOTS;
     const int nsl = min(nslots - base, SB_SLOTS);
     if (win > 0) __syncthreads();
-    for (int i = tid; i < nsl * 2; i += 256) acc[i] = 0.0f;
+    for (int i = tid; i < nsl * 2; i += nthr) acc[i] = 0.0f;
     __syncthreads();
     if (ro < W) {
       const bool fast = C == 32 && W % SB_U == 0;           // block-uniform
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256) void seg_bwd_kernel(const float *__restrict__ 
     }
     __syncthreads();
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
-    for (int i = tid; i < nsl * 2; i += 256) dst[i] = acc[i];
+    for (int i = tid; i < nsl * 2; i += nthr) dst[i] = acc[i];
   }
 }
 
@@ -1363,11 +1363,15 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
                              part_off, P, K, workspace, seg, arg, rec, vslot, stream);
 }
 
-int smplr_seg_bwd_nsplit(int W) { return W > 0 ? (W + smplr::SB_ROWS - 1) / smplr::SB_ROWS : 0; }
+int smplr_seg_bwd_nsplit(int B, int W) {
+  if (B <= 0 || W <= 0) return 0;
+  const int rows = smplr::seg_bwd_rows(B, W);
+  return (W + rows - 1) / rows;
+}
 
 size_t smplr_seg_bwd_workspace(int B, int W) {
   if (B <= 0 || W <= 0) return 0;
-  const int nsplit = (W + smplr::SB_ROWS - 1) / smplr::SB_ROWS;
+  const int nsplit = smplr_seg_bwd_nsplit(B, W);
   return (size_t)B * nsplit * smplr::SB_NWIN * smplr::SB_SLOTS * 2 * sizeof(float);
 }
 
@@ -1379,11 +1383,11 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
   if (B == 0) return 0;
   SMPLR_REQUIRE(dseg && arg && rec && workspace, "smplr_seg_bwd: null pointer");
   hipStream_t st = as_stream(stream);
-  const int nsplit = (W + SB_ROWS - 1) / SB_ROWS;
+  const int rows = seg_bwd_rows(B, W), nsplit = (W + rows - 1) / rows;
   const int S = seg_slots(P, K);
   SMPLR_REQUIRE(S <= SB_NWIN * SB_SLOTS, "smplr_seg_bwd: %d record slots exceed %d", S, SB_NWIN * SB_SLOTS);
-  hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(256), 0, st, dseg, reinterpret_cast<const short *>(arg),
-                     reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, reinterpret_cast<float *>(workspace));
+  hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(32 * rows), 0, st, dseg, reinterpret_cast<const short *>(arg),
+                     reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, reinterpret_cast<float *>(workspace), rows);
   SMPLR_LAUNCH_CHECK("smplr_seg_bwd");
   if (!dproj) return 0;                        // slot sums only: smplr_smpl_bwd gathers them by vertex
   hipLaunchKernelGGL(seg_bwd_merge_kernel, dim3(SB_SLOTS / 256, B), dim3(256), 0, st,

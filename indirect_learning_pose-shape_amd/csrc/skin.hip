@@ -176,16 +176,23 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     const int sl = max(slot, 0), win = sl / SB_SLOTS;
     const float *sp = seg_part + ((size_t)n * seg_nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (sl - win * SB_SLOTS) * 2;
     float sx = 0.0f, sy = 0.0f;
-    constexpr int GC = 6;                     // row blocks requested together (W = 48: all six)
-    for (int s0 = 0; s0 < seg_nsplit; s0 += GC) {
-      float2 t[GC];
+    if (seg_nsplit <= 2) {                    // block-uniform: large batches (24 rows per row block, W <= 48)
+      const float2 t0 = *reinterpret_cast<const float2 *>(sp);
+      const float2 t1 = *reinterpret_cast<const float2 *>(sp + (size_t)(seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
+      sx = t0.x + (seg_nsplit > 1 ? t1.x : 0.0f);
+      sy = t0.y + (seg_nsplit > 1 ? t1.y : 0.0f);
+    } else {
+      constexpr int GC = 6;                   // row blocks requested together (W = 48 at 8 rows: all six)
+      for (int s0 = 0; s0 < seg_nsplit; s0 += GC) {
+        float2 t[GC];
 #pragma unroll
-      for (int u = 0; u < GC; ++u)
-        t[u] = *reinterpret_cast<const float2 *>(sp + (size_t)min(s0 + u, seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
+        for (int u = 0; u < GC; ++u)
+          t[u] = *reinterpret_cast<const float2 *>(sp + (size_t)min(s0 + u, seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
 #pragma unroll
-      for (int u = 0; u < GC; ++u) {
-        sx += (s0 + u < seg_nsplit) ? t[u].x : 0.0f;
-        sy += (s0 + u < seg_nsplit) ? t[u].y : 0.0f;
+        for (int u = 0; u < GC; ++u) {
+          sx += (s0 + u < seg_nsplit) ? t[u].x : 0.0f;
+          sy += (s0 + u < seg_nsplit) ? t[u].y : 0.0f;
+        }
       }
     }
     if (slot >= 0) { gp0 += sx; gp1 += sy; }

@@ -299,7 +299,7 @@ def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True):
     dproj = _empty((B, VP, 3), dseg) if merge else None
     check(lib.smplr_seg_bwd(ptr(dseg), ptr(arg), ptr(rec), B, VP, W, pt.P, pt.K, ptr(dproj), ptr(ws),
                             stream()), "smplr_seg_bwd")
-    return dproj if merge else (ws, int(lib.smplr_seg_bwd_nsplit(W)))
+    return dproj if merge else (ws, int(lib.smplr_seg_bwd_nsplit(B, W)))
 
 
 def argmin_vertices(arg, rec):

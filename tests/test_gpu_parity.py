@@ -732,7 +732,7 @@ def test_seg_backward_many_records_windows(layer, part_tables):
     grad_close(d1.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(seg, windows)")
 
 
-@pytest.mark.parametrize("vs,W,all_visible", [(1, 48, False), (2, 50, False), (1, 48, True)])
+@pytest.mark.parametrize("vs,W,all_visible", [(1, 48, False), (2, 50, False), (1, 48, True), (1, 16, False)])
 def test_seg_gradient_gathered_by_vertex_equals_merged(layer, smpl_model, vs, W, all_visible):
     """The decoder's backward leaves the segmentation gradient as per-row-block slot sums and lets the skinning
     backward gather them by vertex (vslot).  Fed the SAME slot sums, that must equal, bit for bit, merging them
