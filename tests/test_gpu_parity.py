@@ -519,7 +519,7 @@ def test_seg_generic_masks_and_odd_width(layer, part_tables, mask_kind):
 
 @pytest.mark.parametrize("W,nfar,unit", [(48, 300, True), (48, 300, False), (48, 780, False), (48, 950, True),
                                          (48, 1100, True), (32, 300, True), (32, 700, True), (64, 600, False),
-                                         (96, 500, True)])
+                                         (96, 500, True), (128, 400, False), (160, 300, True)])
 def test_seg_record_list_regimes(layer, part_tables, W, nfar, unit):
     """The forward rasteriser picks its pair loop by the length of a mesh's far-reaching record list and by the
     weights: (v - row)^2 row tables in LDS (lists up to ~860 records at W = 48 with unit weights, ~690 otherwise,
