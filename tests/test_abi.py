@@ -54,3 +54,16 @@ def test_argument_counts_match_header():
         params = m.group(1).strip()
         n = 0 if params in ("", "void") else params.count(",") + 1
         assert n == len(args), "%s: header has %d parameters, ctypes table %d" % (name, n, len(args))
+
+
+def test_seg_bwd_row_blocks_by_batch():
+    """The segmentation backward cuts a mesh's image into row blocks of 8 rows, or of 24 once the batch still
+    leaves every CU (256) a block; the workspace is sized for whichever applies (host-side arithmetic only)."""
+    from ilps_amd import _lib
+    lib = _lib.load()
+    assert lib.smplr_seg_bwd_nsplit(1, 48) == 6 and lib.smplr_seg_bwd_nsplit(127, 48) == 6
+    assert lib.smplr_seg_bwd_nsplit(128, 48) == 2 and lib.smplr_seg_bwd_nsplit(2048, 48) == 2
+    assert lib.smplr_seg_bwd_nsplit(64, 96) == 4 and lib.smplr_seg_bwd_nsplit(63, 96) == 12
+    assert lib.smplr_seg_bwd_nsplit(300, 20) == 1 and lib.smplr_seg_bwd_nsplit(0, 48) == 0
+    for B, W in ((1, 48), (128, 48), (64, 96), (5, 50)):
+        assert lib.smplr_seg_bwd_workspace(B, W) == B * lib.smplr_seg_bwd_nsplit(B, W) * 5 * 4096 * 2 * 4
