@@ -1045,9 +1045,10 @@ __device__ __forceinline__ int nearest_bit1(unsigned long long m, int cx) {
   return dl <= dr ? -dl : dr;
 }
 
+constexpr int LPP = 4;     // lanes per pixel (B = 128, W = 48: 2 lanes 49 us, 4: 48.5, 8: 60, 16: 87)
 __device__ __forceinline__ unsigned long long quad_min(unsigned long long k) {
 #pragma unroll
-  for (int o = 1; o <= 2; o <<= 1) {
+  for (int o = 1; o < LPP; o <<= 1) {
     const unsigned int lo = __shfl_xor((unsigned int)k, o, 64), hi = __shfl_xor((unsigned int)(k >> 32), o, 64);
     const unsigned long long other = ((unsigned long long)hi << 32) | lo;
     k = other < k ? other : k;
@@ -1130,8 +1131,9 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
   __syncthreads();
   // ---- pixels: a wave takes 4 x 4 tiles, 4 lanes per pixel
   const int lane = tid & 63;
-  const int sub = lane & 3, pq = lane >> 2;                // lane of the pixel's quad, pixel of the tile
-  const int tpr = (W + 3) / 4, ntile = tpr * tpr;
+  const int sub = lane & (LPP - 1), pq = lane / LPP;       // lane of the pixel's group, pixel of the tile
+  constexpr int TH = 64 / LPP / 4;                         // tile: 4 pixels wide, TH high
+  const int tpr = (W + 3) / 4, ntile = tpr * ((W + TH - 1) / TH);
 #define SMPLR_SILH_VERTEX(i_)                                                                   \
   {                                                                                             \
     const float du_ = sU[i_] - fc, dv_ = sV[i_] - fr;                                           \
@@ -1150,7 +1152,7 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
     if (t >= nloc) break;
     const int tile = t * (int)gridDim.y + (int)blockIdx.y;
     const int ty = tile / tpr, tx = tile - ty * tpr;
-    const int r_ = ty * 4 + (pq >> 2), c_ = tx * 4 + (pq & 3);
+    const int r_ = ty * TH + (pq >> 2), c_ = tx * 4 + (pq & 3);
     const bool live = r_ < W && c_ < W;
     const int r = min(r_, W - 1), c = min(c_, W - 1);      // clamped lanes repeat a border pixel
     const float fc = (float)c, fr = (float)r;
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
     unsigned long long near = ~0ull;                       // (d^2 bits << 32) | cell
     // rows cy, cy +- 1, cy +- 2, ... (this lane: offsets sub, sub + 4, ...); a lane stops once the
     // row offset alone exceeds its own best (such rows cannot beat it, hence not the quad's minimum)
-    for (int k = sub; k < GW; k += 4) {
+    for (int k = sub; k < GW; k += LPP) {
       const float fk = (float)k;
       if ((unsigned long long)__float_as_uint(fk * fk) << 32 > near) break;
 #pragma unroll
@@ -1182,7 +1184,7 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
       {
         const int e = (int)(near & 0xffffffffull);
         const int i0 = e ? s_cnt[e - 1] : 0, i1 = s_cnt[e];
-        for (int i = i0 + sub; i < i1; i += 4) SMPLR_SILH_VERTEX(i)
+        for (int i = i0 + sub; i < i1; i += LPP) SMPLR_SILH_VERTEX(i)
         best = quad_min(best);
       }
       // (3) every occupied cell whose centre is within R = d1 + 0.7072 (+ rounding slack)
@@ -1191,7 +1193,7 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
       const float R2 = R * R * 1.0001f;
       const int rad = (int)R + 1;
       const int ylo = max(0, cy - rad), yhi = min(GW - 1, cy + rad);
-      for (int y = ylo + sub; y <= yhi; y += 4) {
+      for (int y = ylo + sub; y <= yhi; y += LPP) {
         const float dy = (float)(y - cy);
         const float rem = R2 - dy * dy;
         if (rem < 0.0f) continue;
@@ -1217,7 +1219,7 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
         }
       }
     }
-    for (int i = tot_v + sub; i < tot_v + nout; i += 4) SMPLR_SILH_VERTEX(i)     // outliers: always
+    for (int i = tot_v + sub; i < tot_v + nout; i += LPP) SMPLR_SILH_VERTEX(i)     // outliers: always
     best = quad_min(best);
     if (live && sub == 0) {
       float score = 0.0f;
