@@ -723,7 +723,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
           const int sc = __float_as_int(fast_exp_neg(__uint_as_float(rec.x)));
           const int p = (int)rec.y;
           const int old = atomicMax(&rowS[p], sc);
-          const int fin = *reinterpret_cast<volatile int *>(&rowS[p]);
+          const int fin = __hip_atomic_load(&rowS[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (a ds_read, not a flat load)
           if (old < sc && fin == sc) rowA[p] = (short)(lbase + i);
         }
         rec = nxt;
