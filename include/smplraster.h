@@ -136,7 +136,7 @@ int smplr_skin_bwd(const float *dverts, const float *dproj,
  * seg_part / seg_vslot / seg_nsplit (NULL, NULL, 0 to omit): the segmentation rasteriser's gradient as
  * smplr_seg_bwd leaves it when called with dproj = NULL - per-row-block slot sums in its workspace - plus
  * the vertex -> slot map of the forward and smplr_seg_bwd_nsplit(B,W) (row blocks per mesh: 8 image rows each,
- * 24 once the batch still gives every CU a row block).  The skinning backward then gathers
+ * 24 while the batch gives every CU one to four row blocks).  The skinning backward then gathers
  * d(seg)/d(proj) by vertex, summing the row blocks in the order the merge kernel would have (bit-identical),
  * and adds it to dproj (if given): one launch and one (B,VP,3) round trip less.
  * workspace: smplr_smpl_bwd_workspace(B,V) bytes.                                              */

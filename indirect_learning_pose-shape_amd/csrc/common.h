@@ -59,11 +59,14 @@ int skin_bwd_nblk(int V);
 constexpr int SB_SLOTS = 4096;   // 32 KB of LDS accumulators per window
 constexpr int SB_NWIN = 5;       // slot windows the partial buffer holds: S <= 20480
 constexpr int SB_ROWS = 8;       // rows (strips) per block at small batch ...
-constexpr int SB_ROWS_BIG = 24;  // ... and once that still leaves every CU a block: fewer zero / write-out passes
+constexpr int SB_ROWS_BIG = 24;  // ... and while that gives every CU one to four blocks: fewer zero / write-out passes
                                  // over the accumulators and fewer partials per vertex for the gather
                                  // (B = 128: seg_bwd -1.0 us, skin_bwd -0.4; at B = 32 it would cost 4 us)
 inline int seg_bwd_rows(int B, int W) {
-  return ((long long)B * ((W + SB_ROWS_BIG - 1) / SB_ROWS_BIG) >= 256) ? SB_ROWS_BIG : SB_ROWS;
+  // seg_bwd + skin_bwd at W = 48, 8 against 24 rows: B = 128 42.4 / 41.0 us, 256: 81.9 / 78.3, 512: 153.3 / 156.9,
+  // 2048: 578 / 601 - the tall blocks pay off between one and four blocks per CU
+  const long long n = (long long)B * ((W + SB_ROWS_BIG - 1) / SB_ROWS_BIG);
+  return (n >= 256 && n < 1024) ? SB_ROWS_BIG : SB_ROWS;
 }
 struct SegGrad { const float *part; const int16_t *vslot; int nsplit; };
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
