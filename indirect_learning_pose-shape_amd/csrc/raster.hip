@@ -15,13 +15,15 @@
 //      This drops the pair count from 2304 x 6879 to 2304 x (#visible ~ 570) per mesh without
 //      changing a single fp32 result.
 //  (2) raster_fwd_kernel: a lane owns one pixel; a workgroup = 256 consecutive pixels of one mesh
-//      x 4 channel groups (16 waves).  The mesh's global records are copied to LDS once per
-//      block (field-major) and walked four at a time with broadcast ds_read_b128; keys
-//      m^2((u-c)^2 + (v-r)^2) on the packed fp32 pipe, only the minimum of a group is tracked,
-//      and the winning group is re-evaluated once per (pixel, part) for the first arg-min;
-//      score = exp(-sqrt(key)).  The pixel's local records are then merged in.  Scores and
-//      arg-mins go through an LDS tile so the NHWC outputs are written as contiguous 32-B /
-//      16-B pixel segments.  Record lists too long for LDS use scalar loads instead.
+//      x 4 contiguous ranges of parts (16 waves), the ranges cut per mesh so that each holds a
+//      quarter of its global records.  The records are copied to LDS once per block (field-major)
+//      together with (v - row)^2 for the image rows the block touches, so a pair costs a subtract
+//      and an fma on the packed fp32 pipe; eight records per step, the running minimum carried
+//      through v_min3, the winning group re-evaluated once per (pixel, part) for the first arg-min;
+//      score = exp(-sqrt(key)) into a pixel-major LDS tile.  After one barrier all waves merge the
+//      pixels' local records (8 lanes per pixel, LDS atomic max on the score bits) and write the
+//      NHWC outputs as whole 128-B / 64-B pixel rows.  Record lists too long for the tables use
+//      the plain LDS copy, those too long for LDS scalar loads.
 //
 // Backward (seg_bwd_kernel + seg_bwd_merge_kernel): lanes = channels of a pixel exactly as the
 // NHWC tensors lie in memory (coalesced; the 32 lanes of a pixel hit 31 different parts, hence
