@@ -3,7 +3,8 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched with
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
-RCCL).  A "step" is one forward + backward of the full decoder (BASELINE.json configs[2]: batch_smpl +
+RCCL) - and when it is NOT under a launcher (no WORLD_SIZE) it starts those N ranks itself as a fresh child
+process and relays rank 0's line; `--gpus` and WORLD_SIZE disagreeing is an error.  A "step" is one forward + backward of the full decoder (BASELINE.json configs[2]: batch_smpl +
 projection + compute_mask + projects_to_seg, B=128 meshes per GPU, W=48) on seeded synthetic
 parameters that are already resident in HBM.  The path shards by mesh with no data-path collective
 (SURVEY.md §8(e)): every rank processes its own B meshes ("weak" scaling), the timed region is
@@ -210,6 +211,91 @@ def parity_sample(model, consts, pt, W, dev, Bp=2):
             "seg_bar": "|d| <= 1e-3 |ref| + 1e-6", "oracle": "oracle/np_oracle.py (float64)"}
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a FRESH child process
+    (`python -m torch.distributed.run`, one rank per GPU) before this process has touched the GPU, relay rank 0's
+    JSON line and exit with the child's code.  Never exec: replacing a process that has initialised HIP takes the
+    machine down on this pool, and a child keeps the parent free of any GPU state."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    out = proc.stdout.decode("utf-8", "replace")
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        sys.stderr.write("bench: the %d-rank child printed no JSON line\n" % n)
+        return 1
+    return proc.returncode
+
+
+def dry_run(args, rank, world):
+    """`--dry-run`: the N-rank protocol of the bench without a GPU (gloo): per-rank seeded inputs, a CPU stand-in
+    step (parameter conditioning of the rank's own meshes + a rank-dependent sleep), barrier-bracketed timing,
+    MAX over ranks, ONE JSON line from rank 0.  What tests/test_bench_launcher.py checks at world size 2."""
+    import torch.distributed as dist
+    from ilps_amd.keras_smpl.set_cam_params import load_mean_set_cam_params
+    if world > 1:
+        dist.init_process_group("gloo")
+    B, W = args.batch, args.wh
+    seed = 1000 + rank
+    x = torch.tensor(make_x(B, W, seed))
+
+    def step():
+        load_mean_set_cam_params(x, W)
+        time.sleep(0.002 * (rank + 1))
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    work = time.perf_counter() - t0                    # this rank's own steps, before it waits for the others
+    if world > 1:
+        dist.barrier()
+    mine = time.perf_counter() - t0
+    elapsed, seeds, times, sums, works = mine, [seed], [mine], [float(x.double().sum())], [work]
+    if world > 1:
+        tt = torch.tensor([mine], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rows = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor([seed, mine, sums[0], work], dtype=torch.float64))
+        seeds, times, sums, works = ([float(r[i]) for r in rows] for i in range(4))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "meshes/sec fwd+bwd (SMPL->48x48 31-part seg)", "value": round(world * B * args.steps / elapsed, 1),
+            "unit": "meshes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "dry_run": True,
+            "config": {"workload": "DRY RUN (no GPU): launcher / sharding / timing protocol only",
+                       "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W},
+            "rank_seeds": [int(v) for v in seeds], "rank_elapsed_s": times, "rank_work_s": works,
+            "rank_input_checksums": sums}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,11 +308,23 @@ def main():
                     help="concurrent mesh chunks per step (HIP streams / parallel graph branches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run the N-rank launch / timing protocol over gloo with a CPU stand-in step")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the ranks ourselves, BEFORE anything touches the GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree "
+                         "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
     # one rank per GPU; the modulo only matters when several ranks are rehearsed on a one-GPU box

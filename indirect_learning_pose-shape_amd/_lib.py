@@ -104,7 +104,27 @@ def ptr(t):
 
 
 def stream():
+    """torch's current stream on the CURRENT device: call sites run under `on_device`, which makes the
+    operands' device the current one first (a launch on device 0's stream with device-1 pointers faults)."""
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(fn):
+    """Run fn with the device of its first HIP tensor argument as the current device, so that `stream()`,
+    the kernels' launches and torch's allocations all refer to the device the operands live on (autograd
+    switches devices for backward by itself, forward calls do not)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in args:
+            if getattr(a, "is_cuda", False) is True:          # a tensor, or an operand bundle exposing .device
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kw)
+                break
+        return fn(*args, **kw)
+    return wrapper
 
 
 def require_cuda(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:

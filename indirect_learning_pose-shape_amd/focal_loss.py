@@ -14,8 +14,17 @@ for _c in (1, 2, 3, 4, 10, 12, 14, 15, 16, 17, 23, 25):
     CLASS_WEIGHTS[_c] = 2.0
 
 
+_class_w_cache = {}
+
+
 def class_weights(device, dtype=torch.float32):
-    return torch.tensor(CLASS_WEIGHTS, device=device, dtype=dtype)
+    """The fixed weight vector on `device`, uploaded once per (device, dtype): a fresh `torch.tensor(list)` per
+    step is a pageable host-to-device copy, i.e. a host sync in every train step and illegal under graph capture."""
+    key = (str(device), dtype)
+    w = _class_w_cache.get(key)
+    if w is None:
+        w = _class_w_cache[key] = torch.tensor(CLASS_WEIGHTS, device=device, dtype=dtype)
+    return w
 
 
 def categorical_focal_loss(gamma=2.0, weight_classes=False):

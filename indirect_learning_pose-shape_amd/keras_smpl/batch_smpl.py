@@ -90,11 +90,11 @@ class SMPLLayer(nn.Module):
 
     def batch_rodrigues(self, theta, batch_size=None):
         """theta (N,3) -> (N,3,3) via the pose kernel (24 joints per row, zero padded)."""
-        theta = theta.contiguous()
         n = theta.shape[0]
         rows = (n + 23) // 24
-        x = torch.zeros(rows, 82, dtype=torch.float32, device=theta.device)
-        x[:, :72].view(-1, 3)[:n] = theta
+        th = torch.zeros(rows * 24, 3, dtype=torch.float32, device=theta.device)
+        th[:n] = theta
+        x = torch.cat([th.view(rows, 72), th.new_zeros(rows, 10)], dim=1)      # [theta(72) | beta = 0]
         c = self.constants(theta.device)
         _, Rs, _, _, _ = ops._pose_fwd(x, 0, c)
         return Rs.reshape(-1, 3, 3)[:n]

@@ -22,7 +22,11 @@ from .keras_smpl.set_cam_params import load_mean_set_cam_params
 class PReLU(nn.PReLU):
     """`PReLU(shared_axes=[1, 2])` (encoders/encoder_enet_simple.py:21): same parameters and state dict as
     `nn.PReLU(C)`; on a HIP device the forward / backward are the package's kernels (the stock backward is
-    half of the train step: it materialises a per-element slope gradient before reducing it)."""
+    half of the train step: it materialises a per-element slope gradient before reducing it).  The slope starts
+    at 0 as in Keras (`alpha_initializer='zeros'`), not at torch's 0.25."""
+
+    def __init__(self, num_parameters=1, init=0.0, **kw):
+        super().__init__(num_parameters, init=init, **kw)
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and self.weight.numel() == x.shape[1]:

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import KPAD, CHUNK, check, ptr, require_cuda, stream
+from ._lib import KPAD, CHUNK, check, on_device, ptr, require_cuda, stream
 from .smpl_model import SMPLModelData, load_part_tables
 
 
@@ -163,7 +163,16 @@ class PoseCoef:
     def __init__(self, kmajor, frag3, B):
         self.kmajor, self.frag3, self.B = kmajor, frag3, B
 
+    @property
+    def device(self):
+        return (self.kmajor if self.kmajor is not None else self.frag3).device
 
+    @property
+    def is_cuda(self):
+        return self.device.type == "cuda"
+
+
+@on_device
 def _pose_fwd(x, num_cam, c: SMPLConstants, out=None, want=None):
     """want: 'frag3' | 'kmajor' | 'both'; default = what the constants' blend GEMM reads."""
     lib = _lib.load()
@@ -182,6 +191,7 @@ def _pose_fwd(x, num_cam, c: SMPLConstants, out=None, want=None):
     return PoseCoef(km, f3, B), Rs, J, A, Jt
 
 
+@on_device
 def _blend_fwd(coef: PoseCoef, c: SMPLConstants, B, out=None):
     """coef: what _pose_fwd returned for the same B meshes."""
     lib = _lib.load()
@@ -203,6 +213,7 @@ def _blend_fwd(coef: PoseCoef, c: SMPLConstants, B, out=None):
     return v_posed
 
 
+@on_device
 def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_verts=True, out=None):
     lib = _lib.load()
     B = v_posed.shape[0]
@@ -218,6 +229,7 @@ def _skin_fwd(v_posed, A, c: SMPLConstants, cam=None, vertex_sampling=1, want_ve
     return verts, proj
 
 
+@on_device
 def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJt, vertex_sampling=1,
               out=None, seg_grad=None):
     """dverts and/or dproj (+ optional dJ_transformed) -> dx (B, x_stride).
@@ -239,6 +251,7 @@ def _smpl_bwd(x, num_cam, c: SMPLConstants, Rs, J, A, v_posed, dverts, dproj, dJ
     return dx
 
 
+@on_device
 def visibility(proj, grid_wh=64, ref_compat=True, out=None):
     """compute_mask (keras_smpl/compute_mask.py:12-108), stateless; no gradient (:30)."""
     lib = _lib.load()
@@ -252,6 +265,7 @@ def visibility(proj, grid_wh=64, ref_compat=True, out=None):
     return mask
 
 
+@on_device
 def _seg_fwd(proj, mask, W, pt: PartTable, out=None, vslot=None):
     """vslot (B,VP) int16, optional output: each vertex' record slot, for the gather form of the backward."""
     lib = _lib.load()
@@ -270,6 +284,7 @@ def _seg_fwd(proj, mask, W, pt: PartTable, out=None, vslot=None):
     return seg, arg, rec
 
 
+@on_device
 def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None, vslot=None):
     """compute_mask + projects_to_seg in one call (smplr_vis_seg_fwd): -> mask, seg, arg, rec."""
     lib = _lib.load()
@@ -290,6 +305,7 @@ def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None, 
     return mask, seg, arg, rec
 
 
+@on_device
 def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True):
     """merge=True -> dproj (B,VP,3).  merge=False -> (part, nsplit): the per-row-block slot sums, to be handed
     to _smpl_bwd(seg_grad=(part, vslot, nsplit)) which gathers them by vertex (no merge launch, no dproj)."""
@@ -312,6 +328,7 @@ def argmin_vertices(arg, rec):
     return torch.where(flat >= 0, got, torch.full_like(got, -1)).reshape(slots.shape)
 
 
+@on_device
 def _silh_fwd(proj, W, out=None):
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
@@ -325,6 +342,7 @@ def _silh_fwd(proj, W, out=None):
     return silh, arg
 
 
+@on_device
 def _silh_bwd(dsilh, silh, arg, proj, W):
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
@@ -339,6 +357,7 @@ class BatchSMPLFn(torch.autograd.Function):
     """x (B, num_cam+82) -> verts (B,V,3), J_transformed (B,24,3)."""
 
     @staticmethod
+    @on_device
     def forward(ctx, x, consts: SMPLConstants, num_cam: int):
         x = require_cuda(x, "x")
         ctx.set_materialize_grads(False)
@@ -350,6 +369,7 @@ class BatchSMPLFn(torch.autograd.Function):
         return verts, Jt
 
     @staticmethod
+    @on_device
     def backward(ctx, dverts, dJt):
         x, Rs, J, A, v_posed = ctx.saved_tensors
         dverts = require_cuda(dverts, "dverts") if dverts is not None else None
@@ -364,6 +384,7 @@ class ProjectFn(torch.autograd.Function):
     """(verts (B,V,3), smpl (B,>=4)) -> (B,V',3)   (keras_smpl/projection.py:54-81)."""
 
     @staticmethod
+    @on_device
     def forward(ctx, verts, smpl, vertex_sampling: int):
         lib = _lib.load()
         verts = require_cuda(verts, "verts")
@@ -378,6 +399,7 @@ class ProjectFn(torch.autograd.Function):
         return proj
 
     @staticmethod
+    @on_device
     def backward(ctx, dproj):
         lib = _lib.load()
         verts, smpl = ctx.saved_tensors
@@ -396,6 +418,7 @@ class SegRasterFn(torch.autograd.Function):
     """(proj (B,V',3), mask (B,V')) -> seg (B,W,W,32)   (keras_smpl/projects_to_seg.py:9-69)."""
 
     @staticmethod
+    @on_device
     def forward(ctx, proj, mask, img_wh: int, pt: PartTable):
         proj = require_cuda(proj, "projects_with_depth")
         mask = require_cuda(mask, "mask_vals")
@@ -407,6 +430,7 @@ class SegRasterFn(torch.autograd.Function):
         return seg, arg, rec
 
     @staticmethod
+    @on_device
     def backward(ctx, dseg, _darg, _drec):
         arg, rec = ctx.saved_tensors
         if dseg is None:
@@ -419,6 +443,7 @@ class SilhRasterFn(torch.autograd.Function):
     """proj (B,V',3) -> silh (B,W,W,2)   (keras_smpl/projects_to_silhouette.py:14-44)."""
 
     @staticmethod
+    @on_device
     def forward(ctx, proj, img_wh: int):
         proj = require_cuda(proj, "projects_with_depth")
         silh, arg = _silh_fwd(proj, int(img_wh))
@@ -428,6 +453,7 @@ class SilhRasterFn(torch.autograd.Function):
         return silh, arg
 
     @staticmethod
+    @on_device
     def backward(ctx, dsilh, _darg):
         proj, silh, arg = ctx.saved_tensors
         dsilh = require_cuda(dsilh, "dsilh")
@@ -451,6 +477,7 @@ class SoftmaxFocalFn(torch.autograd.Function):
     Targets are data: no gradient.  The softmax is recomputed in backward, not stored."""
 
     @staticmethod
+    @on_device
     def forward(ctx, scores, target, class_w, gamma: float):
         scores = require_cuda(scores, "scores")
         C = scores.shape[-1]
@@ -470,6 +497,7 @@ class SoftmaxFocalFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @on_device
     def backward(ctx, dloss):
         scores, tgt, class_w = ctx.saved_tensors
         dloss = require_cuda(dloss, "dloss")
@@ -480,6 +508,7 @@ class SoftmaxFocalFn(torch.autograd.Function):
         return dscores, None, None, None
 
 
+@on_device
 def softmax_probs(scores):
     """Softmax over the last axis through the loss kernel's forward (the 'segs' model output,
     model.py:119-120); no autograd (use torch.softmax where a gradient through probs is needed)."""
@@ -499,6 +528,7 @@ class PReLUFn(torch.autograd.Function):
     smplr_prelu_fwd / smplr_prelu_bwd.  x (N, C, ...) and weight (C,)."""
 
     @staticmethod
+    @on_device
     def forward(ctx, x, weight):
         x = require_cuda(x, "x")
         weight = require_cuda(weight, "weight")
@@ -513,6 +543,7 @@ class PReLUFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @on_device
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         N, C, HW = ctx.dims
@@ -531,6 +562,7 @@ class BatchNormActFn(torch.autograd.Function):
     running_mean / running_var are updated in place like torch.nn.BatchNorm2d; slope = None: no activation."""
 
     @staticmethod
+    @on_device
     def forward(ctx, x, gamma, beta, slope, running_mean, running_var, eps, momentum):
         lib = _lib.load()
         x = require_cuda(x, "x")
@@ -551,6 +583,7 @@ class BatchNormActFn(torch.autograd.Function):
         return z
 
     @staticmethod
+    @on_device
     def backward(ctx, dz):
         lib = _lib.load()
         x, gamma, beta, slope, mean, rstd = ctx.saved_tensors
@@ -570,6 +603,7 @@ class BatchNormResActFn(torch.autograd.Function):
     SpatialDropout2D -> Add -> PReLU, encoders/encoder_enet_simple.py:56-79) as one op (smplr_bn_res_fwd/bwd)."""
 
     @staticmethod
+    @on_device
     def forward(ctx, x, other, gamma, beta, slope, plane_scale, running_mean, running_var, eps, momentum):
         lib = _lib.load()
         x, other = require_cuda(x, "x"), require_cuda(other, "other")
@@ -588,6 +622,7 @@ class BatchNormResActFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_device
     def backward(ctx, dout):
         lib = _lib.load()
         x, other, gamma, beta, slope, plane_scale, mean, rstd = ctx.saved_tensors
@@ -672,7 +707,7 @@ def _run_chunks(bounds, device, fn):
     if len(bounds) == 1:
         fn(*bounds[0])
         return
-    cur = torch.cuda.current_stream()
+    cur = torch.cuda.current_stream(device)
     streams = _chunk_streams(device, len(bounds))
     for st, (lo, hi) in zip(streams, bounds):
         st.wait_stream(cur)
@@ -696,6 +731,7 @@ class DecoderFn(torch.autograd.Function):
     """
 
     @staticmethod
+    @on_device
     def forward(ctx, x, consts: SMPLConstants, num_cam, img_wh, vertex_sampling, pt: PartTable,
                 grid_wh, ref_compat, with_silh, nchunk=1):
         x = require_cuda(x, "x")
@@ -740,6 +776,7 @@ class DecoderFn(torch.autograd.Function):
         return verts, proj, mask, seg, silh, Jt
 
     @staticmethod
+    @on_device
     def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
         x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot = ctx.saved_tensors
         dseg = require_cuda(dseg, "dseg") if dseg is not None else None

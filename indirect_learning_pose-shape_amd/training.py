@@ -3,8 +3,11 @@ MI355X path: forward (encoder + regressor on stock torch ops, decoder on the HIP
 loss, backward, Adam(lr=1e-4).  Data parallelism replaces `keras.utils.multi_gpu_model`
 (train.py:205-210): one process per GPU, `DistributedDataParallel` over RCCL (backend "nccl"),
 gradients of the encoder/regressor all-reduced in ~25 MiB buckets overlapped with backward; the
-decoder has no parameters and exchanges nothing.  BatchNorm stays local per rank,
-as Keras towers normalise per tower."""
+decoder has no parameters and exchanges nothing.  BatchNorm stays local per rank
+(statistics AND running buffers: `broadcast_buffers=False`), as Keras towers normalise per tower.
+`with_silhouette` adds the silhouette cross-entropy of train_stage2_silhouette.py:226-229 to the same step - the
+reference alternates two separately compiled models over one shared encoder; here both heads come out of one
+decoder pass and one backward - at its own resolution `silh_wh` (`silhs_output_wh`, :72-86)."""
 from __future__ import annotations
 
 import os
@@ -23,18 +26,18 @@ class SegTrainer:
 
     def __init__(self, smpl_path=None, input_wh=256, output_wh=48, encoder_architecture="enet", use_IEF=True,
                  weight_classes=True, gamma=2.0, lr=1e-4, device=None, ddp=False, bucket_mb=25,
-                 with_silhouette=False):
+                 with_silhouette=False, silh_wh=None):
         self.device = (torch.device(device) if device is not None
                        else torch.device("cuda", torch.cuda.current_device()))
         self.output_wh = output_wh
         self.smpl_model = SMPLRegressor(output_wh, encoder_architecture, use_IEF).to(self.device)
-        self.decoder = SMPLDecoder(smpl_path, img_wh=output_wh, with_silhouette=with_silhouette)
+        self.decoder = SMPLDecoder(smpl_path, img_wh=output_wh, with_silhouette=with_silhouette, silh_wh=silh_wh)
         self.with_silhouette = with_silhouette
         self.net = self.smpl_model
         if ddp:
             self.net = nn.parallel.DistributedDataParallel(
                 self.smpl_model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
-                bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True)
+                bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
         self.loss_fn = softmax_focal_loss(gamma, weight_classes)      # softmax + focal loss, one HIP kernel
         self.silh_loss_fn = softmax_focal_loss(0.0, False)            # softmax + categorical CE
         self.opt = torch.optim.Adam(self.smpl_model.parameters(), lr=lr)       # train.py:179

@@ -1,0 +1,52 @@
+"""bench.py's N-rank contract without a GPU: `python bench.py --gpus 2 --dry-run` must start two ranks ITSELF
+(fresh child process, torch.distributed.run, gloo), give every rank its own seeded inputs, bracket the timed
+steps with barriers, take the MAX over ranks and print ONE JSON line from rank 0; a --gpus / WORLD_SIZE mismatch
+under a launcher must fail."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=240):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e,
+                          timeout=timeout)
+
+
+def test_gpus_2_launches_two_ranks_itself():
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "6", "--dry-run"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                       # ONE line on stdout, rank 0's
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 12 and d["config"]["meshes_per_gpu"] == 6
+    assert d["rank_seeds"] == [1000, 1001]              # per-rank inputs differ ...
+    assert d["rank_input_checksums"][0] != d["rank_input_checksums"][1]
+    # ... the reported time is the MAX over ranks of the barrier-bracketed region, hence >= every rank's own work
+    # (rank 1's stand-in step sleeps twice as long as rank 0's)
+    elapsed = d["ms_per_step"] * d["steps"] * 1e-3
+    assert abs(elapsed - max(d["rank_elapsed_s"])) < 1e-9
+    assert elapsed >= max(d["rank_work_s"]) and d["rank_work_s"][1] > d["rank_work_s"][0]
+    assert abs(d["value"] - 12 * 4 / elapsed) < 0.1     # whole-job rate: all ranks' meshes / max time
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0
+    assert b"--gpus 4" in r.stderr and b"WORLD_SIZE=2" in r.stderr
+    assert r.stdout.strip() == b""
+
+
+def test_single_rank_default_needs_no_launcher():
+    r = _run(["--steps", "2", "--warmup", "0", "--batch", "3", "--dry-run"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip())
+    assert d["n_gpus"] == 1 and d["rank_seeds"] == [1000]

@@ -1,0 +1,207 @@
+"""GPU parity at the sizes BASELINE.json quotes (one-GPU legs):
+
+  configs[1]  batch_smpl fwd+bwd only, B = 256
+  configs[3]  end-to-end train step (ENet + IEF + decoder + focal loss + Adam), 48x48, B = 256
+  configs[4]  decoder with BOTH heads (31-part segmentation + silhouette), 128 meshes per GPU
+
+The float64 oracle is run on sampled rows (every op of the path is independent per mesh); the other rows
+are pinned by row independence: the big batch must reproduce the rows computed 32 at a time, bit for bit
+in the forward.  Plus the intermediates (Rs, J, A) and the reference class's exported helpers
+(batch_smpl.py:168, :230, :255) against the oracle's."""
+import numpy as np
+import pytest
+import torch
+
+from _inputs import make_x
+from test_gpu_parity import VERT_ATOL, SEG_RTOL, SEG_ATOL, grad_close, t
+
+pytestmark = pytest.mark.gpu
+
+ROWS_256 = [0, 31, 32, 127, 128, 255]
+
+
+def test_config1_batch_smpl_B256(smpl_model):
+    """BASELINE configs[1]: BatchSMPLFn forward + backward at B = 256 (8 mesh tiles; the split-K backward's slice
+    geometry at its largest tested size)."""
+    from ilps_amd.keras_smpl.batch_smpl import SMPLLayer
+    from oracle import np_oracle as o
+    from oracle.torch_oracle import TorchSMPL
+    B = 256
+    x = make_x(B, 48, seed=256)
+    rng = np.random.default_rng(256)
+    gv = rng.normal(0, 1, (B, 6890, 3)).astype(np.float32)
+    gj = rng.normal(0, 1, (B, 24, 3)).astype(np.float32)
+    layer = SMPLLayer(smpl_model)
+    xg = t(x).requires_grad_(True)
+    verts = layer(xg)
+    jt = layer.J_transformed
+    ((verts * t(gv)).sum() + (jt * t(gj)).sum()).backward()
+    torch.cuda.synchronize()
+    assert verts.shape == (B, 6890, 3) and jt.shape == (B, 24, 3)
+    # sampled rows against the float64 oracle: forward ...
+    ref = o.smpl_layer_call(x[ROWS_256].astype(np.float64), smpl_model, return_all=True)
+    assert np.abs(verts[ROWS_256].detach().cpu().numpy() - ref["verts"]).max() <= VERT_ATOL
+    assert np.abs(jt[ROWS_256].detach().cpu().numpy() - ref["J_transformed"]).max() <= VERT_ATOL
+    # ... and gradient (float64 autograd of the same rows with the same cotangents)
+    xo = torch.tensor(x[ROWS_256], dtype=torch.float64, requires_grad=True)
+    vo, jo, _ = TorchSMPL(smpl_model)(xo, return_all=True)
+    ((vo * torch.tensor(gv[ROWS_256], dtype=torch.float64)).sum()
+     + (jo * torch.tensor(gj[ROWS_256], dtype=torch.float64)).sum()).backward()
+    got, want = xg.grad[ROWS_256].cpu().numpy(), xo.grad.numpy()
+    assert np.all(got[:, :4] == 0)
+    grad_close(got[:, 4:76], want[:, 4:76], name="dtheta B=256")
+    grad_close(got[:, 76:], want[:, 76:], name="dbeta B=256")
+    # every row: independent of the batch it was computed in (8 x 32)
+    for lo in range(0, B, 32):
+        xs = t(x[lo:lo + 32]).requires_grad_(True)
+        v2 = layer(xs)
+        j2 = layer.J_transformed
+        ((v2 * t(gv[lo:lo + 32])).sum() + (j2 * t(gj[lo:lo + 32])).sum()).backward()
+        assert torch.equal(v2, verts[lo:lo + 32]), "verts rows %d.." % lo
+        assert torch.equal(j2, jt[lo:lo + 32]), "J_transformed rows %d.." % lo
+        grad_close(xg.grad[lo:lo + 32].cpu().numpy(), xs.grad.cpu().numpy(), 1e-4, "dx rows %d.." % lo)
+    assert torch.isfinite(xg.grad).all()
+
+
+def test_smpl_intermediates_and_exported_helpers(smpl_model):
+    """Rs, J, A of the pose kernel against np_oracle.smpl_layer_call(return_all=True), and the reference class's
+    public helpers batch_rodrigues / batch_skew / batch_global_rigid_transformation (batch_smpl.py:255, :230, :168)
+    against the oracle's restatements - batch_rodrigues with n = 48 and n = 50 rows (more than one 24-joint row of
+    the pose kernel it runs on, and a ragged last row)."""
+    from ilps_amd import ops
+    from ilps_amd.keras_smpl.batch_smpl import SMPLLayer
+    from oracle import np_oracle as o
+    B = 7
+    x = make_x(B, 48, seed=77)
+    layer = SMPLLayer(smpl_model)
+    c = layer.constants(t(x).device)
+    _, Rs, J, A, Jt = ops._pose_fwd(t(x), 4, c)
+    ref = o.smpl_layer_call(x.astype(np.float64), smpl_model, return_all=True)
+    assert np.abs(Rs.cpu().numpy().reshape(B, 24, 3, 3) - ref["Rs"]).max() <= 2e-6
+    assert np.abs(J.cpu().numpy() - ref["J"]).max() <= 2e-6
+    assert np.abs(A.cpu().numpy().reshape(B, 24, 3, 4) - ref["A"][:, :, :3, :]).max() <= 1e-5
+    assert np.abs(Jt.cpu().numpy() - ref["J_transformed"]).max() <= 1e-5
+    rng = np.random.default_rng(4)
+    for n in (48, 50, 1):
+        th = rng.normal(0, 0.7, (n, 3)).astype(np.float32)
+        got = layer.batch_rodrigues(t(th))
+        assert got.shape == (n, 3, 3)
+        assert np.abs(got.cpu().numpy() - o.batch_rodrigues(th.astype(np.float64))).max() <= 2e-6
+    v = rng.normal(0, 1, (9, 3)).astype(np.float32)
+    assert np.array_equal(SMPLLayer.batch_skew(t(v)).cpu().numpy(), o.batch_skew(v).astype(np.float32))
+    Rs64, J64 = ref["Rs"], ref["J"]
+    nj, A4 = SMPLLayer.batch_global_rigid_transformation(t(Rs64), t(J64), smpl_model.parents)
+    wj, wA = o.batch_global_rigid_transformation(Rs64, J64, np.asarray(smpl_model.parents))
+    assert nj.shape == (B, 24, 3) and A4.shape == (B, 24, 4, 4)
+    assert np.abs(nj.cpu().numpy() - wj).max() <= 1e-5 and np.abs(A4.cpu().numpy() - wA).max() <= 1e-5
+    with pytest.raises(NotImplementedError):
+        SMPLLayer.batch_global_rigid_transformation(t(Rs64), t(J64), smpl_model.parents, rotate_base=True)
+
+
+def test_config4_decoder_seg_and_silhouette_B128(smpl_model, part_tables):
+    """BASELINE configs[4], one-GPU leg: 128 meshes through the decoder with both heads, forward + backward.
+    Rows {0, 63, 127} against the float64 oracle (verts, seg, silhouette, dx with the HIP mask injected: visibility
+    is discrete), all rows against the same rows run 32 at a time."""
+    from ilps_amd.decoder import SMPLDecoder
+    from oracle import np_oracle as o
+    from oracle import torch_oracle as to
+    W, B = 48, 128
+    x = make_x(B, W, seed=4128)
+    rng = np.random.default_rng(8)
+    gs = rng.normal(0, 1, (B, W, W, 32)).astype(np.float32)
+    gl = rng.normal(0, 1, (B, W, W, 2)).astype(np.float32)
+    dec = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=True)
+    xg = t(x).requires_grad_(True)
+    out = dec(xg)
+    ((out["seg"] * t(gs)).sum() + (out["silhouette"] * t(gl)).sum()).backward()
+    torch.cuda.synchronize()
+    assert out["seg"].shape == (B, W, W, 32) and out["silhouette"].shape == (B, W, W, 2)
+    rows = [0, 63, 127]
+    ids, off = part_tables[1]
+    proj = out["projects"][rows].detach().cpu().numpy().astype(np.float64)
+    mask = out["mask"][rows].cpu().numpy()
+    assert np.array_equal(mask, o.compute_mask(proj))
+    ref_v = o.smpl_layer_call(x[rows].astype(np.float64), smpl_model)
+    assert np.abs(out["verts"][rows].detach().cpu().numpy() - ref_v).max() <= VERT_ATOL
+    want_seg = o.projects_to_seg(proj, mask, W, ids, off)
+    got_seg = out["seg"][rows].detach().cpu().numpy()
+    assert np.all(np.abs(got_seg - want_seg) <= SEG_RTOL * np.abs(want_seg) + SEG_ATOL)
+    want_sil = o.projects_to_silhouette(proj, W)
+    got_sil = out["silhouette"][rows].detach().cpu().numpy()
+    assert np.all(np.abs(got_sil - want_sil) <= SEG_RTOL * np.abs(want_sil) + SEG_ATOL)
+    xo = torch.tensor(x[rows], dtype=torch.float64, requires_grad=True)
+    mo = torch.tensor(mask, dtype=torch.float64)
+    _, po, _, so = to.decoder_forward(to.TorchSMPL(smpl_model), xo, lambda p: mo, W, ids, off)
+    ((so * torch.tensor(gs[rows], dtype=torch.float64)).sum()
+     + (to.projects_to_silhouette(po, W) * torch.tensor(gl[rows], dtype=torch.float64)).sum()).backward()
+    got, want = xg.grad[rows].cpu().numpy(), xo.grad.numpy()
+    for sl, name in ((slice(0, 4), "dcam"), (slice(4, 76), "dtheta"), (slice(76, 86), "dbeta")):
+        grad_close(got[:, sl], want[:, sl], 5e-3, name + " (seg+silh, B=128)", elem_atol=2e-3)
+    for lo in range(0, B, 32):
+        xs = t(x[lo:lo + 32]).requires_grad_(True)
+        o2 = dec(xs)
+        ((o2["seg"] * t(gs[lo:lo + 32])).sum() + (o2["silhouette"] * t(gl[lo:lo + 32])).sum()).backward()
+        for k in ("verts", "projects", "mask", "seg", "silhouette"):
+            assert torch.equal(o2[k], out[k][lo:lo + 32]), "%s rows %d.." % (k, lo)
+        grad_close(xg.grad[lo:lo + 32].cpu().numpy(), xs.grad.cpu().numpy(), 1e-4, "dx rows %d.." % lo)
+    assert torch.isfinite(xg.grad).all()
+
+
+def test_config3_train_step_B256(smpl_model):
+    """BASELINE configs[3]: SegTrainer.step at B = 256 (ENet on 256x256 inputs + IEF + decoder at 48x48 + softmax-
+    focal loss + Adam).  Finite loss and gradients, the decoder's outputs on the regressed parameters equal to the
+    same rows run 32 at a time (and to the oracle's vertices on sampled rows), and the loss on a fixed batch drops
+    over 3 steps."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.smpl_model import mean86
+    from ilps_amd.training import SegTrainer
+    from oracle import np_oracle as o
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    B, W = 256, 48
+    tr = SegTrainer(smpl_model, output_wh=W, encoder_architecture="enet", use_IEF=True, lr=1e-4, device=dev)
+    tr.smpl_model.train()
+    images = torch.rand(B, 3, 256, 256, device=dev)
+    xl = torch.tensor(np.tile(mean86(W), (B, 1)), dtype=torch.float32, device=dev)
+    xl[:, 4:76] += 0.1 * torch.randn(B, 72, device=dev)
+    dec = SMPLDecoder(smpl_model, img_wh=W)
+    with torch.no_grad():
+        labels = dec(xl)["seg"].argmax(-1)
+    losses = [float(tr.step(images, labels)) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    grads = [p.grad for p in tr.smpl_model.parameters() if p.grad is not None]
+    assert len(grads) > 100 and all(bool(torch.isfinite(g).all()) for g in grads)
+    assert float(tr.smpl_model.backbone.enet.init_conv.weight.grad.abs().sum()) > 0
+    assert losses[-1] < losses[0], losses
+    tr.smpl_model.eval()
+    with torch.no_grad():
+        param = tr.smpl_model(images)
+        full = tr.decoder(param)
+        for lo in range(0, B, 32):
+            part = tr.decoder(param[lo:lo + 32].contiguous())
+            for k in ("verts", "mask", "seg"):
+                assert torch.equal(part[k], full[k][lo:lo + 32]), "%s rows %d.." % (k, lo)
+    ref = o.smpl_layer_call(param[ROWS_256].cpu().numpy().astype(np.float64), smpl_model)
+    assert np.abs(full["verts"][ROWS_256].cpu().numpy() - ref).max() <= VERT_ATOL
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second HIP device")
+def test_ops_follow_their_operands_device(smpl_model):
+    """Operands on cuda:1 while cuda:0 is the current device: the launches must go to the operands' device
+    (every C-ABI call site enters a device guard), forward and backward."""
+    from ilps_amd.decoder import SMPLDecoder
+    W, B = 48, 3
+    x = make_x(B, W, seed=5)
+    g = np.random.default_rng(5).normal(0, 1, (B, W, W, 32)).astype(np.float32)
+    res = []
+    for d in ("cuda:0", "cuda:1"):
+        torch.cuda.set_device(0)
+        dec = SMPLDecoder(smpl_model, img_wh=W)
+        xg = torch.tensor(x, device=d, requires_grad=True)
+        out = dec(xg)
+        (out["seg"] * torch.tensor(g, device=d)).sum().backward()
+        torch.cuda.synchronize(d)
+        assert out["seg"].device == torch.device(d) and xg.grad.device == torch.device(d)
+        res.append((out["verts"].detach().cpu(), out["seg"].detach().cpu(), xg.grad.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    grad_close(res[1][2].numpy(), res[0][2].numpy(), 1e-5, "dx cuda:1 vs cuda:0")
