@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMPLR_ABI_VERSION 3
+#define SMPLR_ABI_VERSION 4
 #define SMPLR_NJ 24            /* joints                                   */
 #define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
 #define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
@@ -197,6 +197,19 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
                       const int32_t *part_pos, const int32_t *part_off, int P, int K,
                       void *workspace, float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot,
                       void *stream);
+
+/* The two stages of smplr_seg_fwd / smplr_vis_seg_fwd as separate entry points (one launch each; calling
+ * them back to back IS the fused call, bit for bit) - for callers that re-rasterise a binned batch and for
+ * timing the pair loop (the dominant kernel) by itself:
+ *   smplr_seg_bin     binning: proj (+ mask) -> rec, vslot and the workspace's per-mesh part offsets and pixel
+ *                     lists.  grid_wh > 0: compute_mask runs inside (mask is an OUTPUT, as in smplr_vis_seg_fwd);
+ *                     grid_wh = 0: mask is an INPUT (as in smplr_seg_fwd).
+ *   smplr_seg_raster  the rasteriser proper over that workspace + rec -> seg, arg.                  */
+int smplr_seg_bin(const float *proj, float *mask, int B, int VP, int W, int grid_wh, int ref_compat,
+                  const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace, float *rec,
+                  int16_t *vslot, void *stream);
+int smplr_seg_raster(int B, int W, int P, int K, const void *workspace, const float *rec, float *seg,
+                     int16_t *arg, void *stream);
 
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:

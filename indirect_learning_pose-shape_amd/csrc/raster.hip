@@ -1316,14 +1316,15 @@ size_t smplr_seg_workspace(int B, int VP, int W, int P, int K) {
 }
 
 namespace smplr {
-static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fuse_vis, int grid_wh, int ref_compat,
+// stage 1: binning (optionally with compute_mask fused in front) -> rec, workspace (part offsets, pixel lists), vslot
+static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fuse_vis, int grid_wh, int ref_compat,
                         int B, int VP, int W, const int32_t *part_pos, const int32_t *part_off, int P, int K,
-                        void *workspace, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
+                        void *workspace, float *rec, int16_t *vslot, void *stream) {
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
                 "%s: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, VP, W, P, K);
   SMPLR_REQUIRE(!fuse_vis || (grid_wh > 0 && grid_wh <= 128), "%s: bad grid_wh=%d (max 128)", fn, grid_wh);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && seg && arg && rec, "%s: null pointer", fn);
+  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && rec, "%s: null pointer", fn);
   hipStream_t st = as_stream(stream);
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
@@ -1355,14 +1356,52 @@ static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fus
   else SMPLR_BIN_LAUNCH(false, false)
 #undef SMPLR_BIN_LAUNCH
   SMPLR_LAUNCH_CHECK(fn);
+  return 0;
+}
+
+// stage 2: the pair loop + merge + write-out over a binned workspace
+static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const void *workspace, const float *rec,
+                           float *seg, int16_t *arg, void *stream) {
+  SMPLR_REQUIRE(B >= 0 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
+                "%s: bad sizes B=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, W, P, K);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(workspace && rec && seg && arg, "%s: null pointer", fn);
+  const SegWs ws = seg_ws_layout(B, W, P, K);
+  const int S = seg_slots(P, K);
+  const char *base = reinterpret_cast<const char *>(workspace);
   const int ntiles = (W * W + RTS - 1) / RTS;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
-  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RTS * NG), 0, st, G, goff, lstart, lrec, P, K, S, W, B, ntiles,
-                     seg, reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W));
+  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RTS * NG), 0, as_stream(stream),
+                     reinterpret_cast<const float4 *>(rec), reinterpret_cast<const int *>(base + ws.goff_off),
+                     reinterpret_cast<const int *>(base + ws.lstart_off),
+                     reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, seg,
+                     reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W));
   SMPLR_LAUNCH_CHECK(fn);
   return 0;
 }
+
+static int seg_fwd_impl(const char *fn, const float *proj, float *mask, bool fuse_vis, int grid_wh, int ref_compat,
+                        int B, int VP, int W, const int32_t *part_pos, const int32_t *part_off, int P, int K,
+                        void *workspace, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
+  SMPLR_REQUIRE(B == 0 || (seg && arg), "%s: null pointer", fn);
+  int rc = seg_bin_impl(fn, proj, mask, fuse_vis, grid_wh, ref_compat, B, VP, W, part_pos, part_off, P, K, workspace,
+                        rec, vslot, stream);
+  if (rc) return rc;
+  return seg_raster_impl(fn, B, W, P, K, workspace, rec, seg, arg, stream);
+}
 }  // namespace smplr
+
+int smplr_seg_bin(const float *proj, float *mask, int B, int VP, int W, int grid_wh, int ref_compat,
+                  const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace, float *rec,
+                  int16_t *vslot, void *stream) {
+  return smplr::seg_bin_impl("smplr_seg_bin", proj, mask, grid_wh > 0, grid_wh, ref_compat, B, VP, W, part_pos,
+                             part_off, P, K, workspace, rec, vslot, stream);
+}
+
+int smplr_seg_raster(int B, int W, int P, int K, const void *workspace, const float *rec, float *seg, int16_t *arg,
+                     void *stream) {
+  return smplr::seg_raster_impl("smplr_seg_raster", B, W, P, K, workspace, rec, seg, arg, stream);
+}
 
 int smplr_seg_fwd(const float *proj, const float *mask, int B, int VP, int W, const int32_t *part_pos,
                   const int32_t *part_off, int P, int K, void *workspace, float *seg, int16_t *arg,

@@ -306,6 +306,36 @@ def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None, 
 
 
 @on_device
+def _seg_bin(proj, mask, W, pt: PartTable, grid_wh=0, ref_compat=True, rec=None, vslot=None, ws=None):
+    """Stage 1 of the segmentation forward alone (smplr_seg_bin): grid_wh > 0 computes the mask inside (output),
+    grid_wh = 0 reads it.  -> (ws, rec): what _seg_raster needs."""
+    lib = _lib.load()
+    B, VP = proj.shape[0], proj.shape[1]
+    if VP != pt.VP:
+        raise RuntimeError("projects has %d vertices but the part table expects %d" % (VP, pt.VP))
+    if ws is None:
+        ws = _workspace(lib.smplr_seg_workspace(B, VP, W, pt.P, pt.K), proj)
+    if rec is None:
+        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), proj)
+    check(lib.smplr_seg_bin(ptr(proj), ptr(mask), B, VP, W, int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos),
+                            ptr(pt.part_off), pt.P, pt.K, ptr(ws), ptr(rec), ptr(vslot), stream()), "smplr_seg_bin")
+    return ws, rec
+
+
+@on_device
+def _seg_raster(ws, rec, B, W, pt: PartTable, out=None):
+    """Stage 2 alone (smplr_seg_raster) over a binned workspace -> seg, arg."""
+    lib = _lib.load()
+    if out is not None:
+        seg, arg = out
+    else:
+        seg = _empty((B, W, W, pt.P + 1), rec)
+        arg = _empty((B, W, W, 32), rec, torch.int16)
+    check(lib.smplr_seg_raster(B, W, pt.P, pt.K, ptr(ws), ptr(rec), ptr(seg), ptr(arg), stream()), "smplr_seg_raster")
+    return seg, arg
+
+
+@on_device
 def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True):
     """merge=True -> dproj (B,VP,3).  merge=False -> (part, nsplit): the per-row-block slot sums, to be handed
     to _smpl_bwd(seg_grad=(part, vslot, nsplit)) which gathers them by vertex (no merge launch, no dproj)."""

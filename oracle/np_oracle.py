@@ -178,6 +178,31 @@ def compute_mask(projects_with_depth, grid_wh=64, ref_compat=True):
     return masks
 
 
+def compute_mask_sorted(projects_with_depth, grid_wh=64, ref_compat=True):
+    """The same stateless definition as `compute_mask` (compute_mask.py:12-108) without the Python loop over the
+    4096 grid cells: one lexicographic sort per sample by (cell, -z, index); the first vertex of every cell group
+    is its arg-max-z, lowest index on ties (`tf.argmax`, :98-103).  Used by the timed CPU baseline so that it does
+    not time the interpreter; pinned to `compute_mask` in tests/test_oracle_kat.py."""
+    p = np.asarray(projects_with_depth, F)
+    B, V = p.shape[0], p.shape[1]
+    masks = np.full((B, V), 500.0, F)
+    idx = np.arange(V)
+    for n in range(B):
+        pu, pv = np.rint(p[n, :, 0]), np.rint(p[n, :, 1])               # :22
+        inside = (pu >= 0) & (pu < grid_wh) & (pv >= 0) & (pv < grid_wh)
+        ii = idx[inside]
+        cell = (pv[inside] * grid_wh + pu[inside]).astype(np.int64)
+        z = p[n, inside, 2] + 0.0                                        # -0.0 ties with +0.0
+        order = np.lexsort((ii, -z, cell))                               # last key is the primary one
+        cs = cell[order]
+        first = np.ones(cs.shape[0], bool)
+        first[1:] = cs[1:] != cs[:-1]
+        masks[n, ii[order][first]] = 1.0
+        if int(first.sum()) < grid_wh * grid_wh and ref_compat and V > 1:   # an empty cell: vertex 1 (:99)
+            masks[n, 1] = 1.0
+    return masks
+
+
 # --------------------------------------------------------------------------- rasterisers
 def _grid(img_wh):
     """`projects_to_seg.py:26-31`: pixel q = r*W + c has coordinate (x=c, y=r)."""

@@ -152,6 +152,52 @@ def decoder_forward(smpl: TorchSMPL, x, mask_fn, img_wh, part_ids, part_off,
     return verts, proj, mask, seg
 
 
+def seg_streaming_fwd_bwd(proj, mask_vals, dseg, img_wh, part_ids, part_off, chunk=8):
+    """projects_to_seg forward + its gradient w.r.t. `proj` WITHOUT the reference's materialised
+    (N, W*W, n_p, 2) tiles or an autograd tape: per part a (W*W, n_p) distance block, min over the part's
+    vertices (`exp` is monotone: max_v exp(-m d) = exp(-min_v m d), projects_to_seg.py:53-56), the score from the
+    winner only, and the TF gradient rules written out (gradient to the arg-min vertex,
+    background passes -upstream while 0 <= sum <= 1, 0 at d = 0).  The CPU baseline's "streaming" leg: the same
+    arithmetic as the dense restatement, the algorithmic reformulation the GPU path also uses, none of its
+    pruning.  -> (seg (N,W,W,32), dproj (N,V',3)); checked against the dense autograd form in tests."""
+    N, W = proj.shape[0], img_wh
+    npix = W * W
+    grid = _grid(W, proj.dtype)                                        # (npix, 2), pixel q = r * W + c
+    P = len(part_off) - 1
+    best = torch.empty(N, npix, P, dtype=proj.dtype)
+    arg = torch.empty(N, npix, P, dtype=torch.long)
+    idxs = [torch.as_tensor(part_ids[part_off[p]:part_off[p + 1]], dtype=torch.long) for p in range(P)]
+    for n0 in range(0, N, chunk):
+        pr = proj[n0:n0 + chunk, :, :2]
+        for p, idx in enumerate(idxs):
+            pp = pr[:, idx, :]                                           # (c, n_p, 2)
+            du = pp[:, None, :, 0] - grid[None, :, None, 0]             # (c, npix, n_p)
+            dv = pp[:, None, :, 1] - grid[None, :, None, 1]
+            x = torch.sqrt(du * du + dv * dv) * mask_vals[n0:n0 + chunk, idx][:, None, :]
+            m, a = x.min(dim=2)
+            best[n0:n0 + chunk, :, p] = m
+            arg[n0:n0 + chunk, :, p] = idx[a]
+    score = torch.exp(-best)                                           # (N, npix, P)
+    ssum = score.sum(dim=2)
+    seg = torch.cat([(1.0 - ssum.clamp(0.0, 1.0)).unsqueeze(2), score], dim=2).reshape(N, W, W, P + 1)
+    seg = torch.flip(seg, dims=[1])
+    # backward
+    g = torch.flip(dseg, dims=[1]).reshape(N, npix, P + 1)
+    gate = ((ssum >= 0.0) & (ssum <= 1.0)).to(proj.dtype).unsqueeze(2)
+    gs = g[:, :, 1:] - gate * g[:, :, :1]                              # d loss / d score
+    pw = torch.gather(proj[:, :, :2].unsqueeze(1).expand(N, npix, proj.shape[1], 2), 2,
+                      arg.unsqueeze(3).expand(N, npix, P, 2))          # winners' positions (N, npix, P, 2)
+    diff = pw - grid[None, :, None, :]
+    d = torch.sqrt((diff * diff).sum(dim=3))
+    mw = torch.gather(mask_vals.unsqueeze(1).expand(N, npix, mask_vals.shape[1]), 2, arg)
+    k = torch.where(d > 0, -gs * score * mw / d.clamp_min(1e-30), torch.zeros_like(d))
+    dproj = torch.zeros_like(proj)
+    flat = arg.reshape(N, -1)
+    for c in range(2):
+        dproj[:, :, c].scatter_add_(1, flat, (k * diff[..., c]).reshape(N, -1))
+    return seg, dproj
+
+
 # --------------------------------------------------------------------------- loss head
 def softmax_focal_loss(scores, y_true, gamma=2.0, class_w=None):
     """`model.py:119-120` + `focal_loss.py:10-46`, differentiable: raw scores (N, W, W, C) or

@@ -720,6 +720,29 @@ def test_vis_seg_fused_equals_separate(layer, vs, W, ref_compat):
         assert np.array_equal(order(ra), order(rb))
 
 
+def test_seg_stages_equal_fused_call(layer, part_tables):
+    """smplr_seg_bin + smplr_seg_raster (the two launches as separate entry points) == smplr_vis_seg_fwd /
+    smplr_seg_fwd, bit for bit, with the mask computed inside and with the mask given."""
+    from ilps_amd import ops
+    W = 48
+    _, _, proj = _decoder_inputs(layer, 5, W, 97)
+    proj = proj.detach()
+    pt = ops.get_part_table(1, proj.device)
+    vs1 = torch.empty(5, pt.VP, dtype=torch.int16, device=proj.device)
+    mask, seg, arg, rec = ops._vis_seg_fwd(proj, W, pt, vslot=vs1)
+    m2 = torch.empty_like(mask)
+    vs2 = torch.empty_like(vs1)
+    ws, rec2 = ops._seg_bin(proj, m2, W, pt, grid_wh=64, vslot=vs2)
+    seg2, arg2 = ops._seg_raster(ws, rec2, 5, W, pt)
+    used = int(rec[0, -1, 0].view(torch.int32))
+    assert torch.equal(m2, mask) and torch.equal(seg2, seg) and torch.equal(arg2, arg) and torch.equal(vs1, vs2)
+    assert used > 0 and torch.equal(rec2[0, :used], rec[0, :used])
+    seg3, arg3, _ = ops._seg_fwd(proj, mask, W, pt)
+    ws4, rec4 = ops._seg_bin(proj, mask, W, pt, grid_wh=0)
+    seg4, arg4 = ops._seg_raster(ws4, rec4, 5, W, pt)
+    assert torch.equal(seg4, seg3) and torch.equal(arg4, arg3) and torch.equal(seg3, seg)
+
+
 def test_seg_backward_many_records_windows(layer, part_tables):
     """A mesh whose record list (> 4096 slots: every vertex marked visible) needs several slot windows
     in seg_bwd, next to a standard single-window mesh: repeatable to rounding, equal to the float64

@@ -236,3 +236,38 @@ def test_focal_torch_oracle_matches_numpy():
     a = o.categorical_focal_loss(y, o.softmax_last(s), 2.0, True)
     b = to.softmax_focal_loss(torch.tensor(s), torch.tensor(y), 2.0, torch.tensor(o.FOCAL_CLASS_WEIGHTS)).numpy()
     assert np.allclose(a, b, rtol=1e-12)
+
+
+def test_sorted_mask_equals_loop_mask(smpl_model):
+    """The vectorised visibility used by the timed CPU baseline == the cell-by-cell restatement."""
+    rng = np.random.default_rng(3)
+    p = (rng.random((3, 6890, 3)) * 80 - 8).astype(np.float32).astype(np.float64)   # collisions, out-of-grid, ties
+    p[0, 100:140, 2] = p[0, 100, 2]                         # equal depths
+    p[0, 100:140, :2] = [10.2, 20.4]
+    p[1, 5, 2], p[1, 6, 2], p[1, 5, :2], p[1, 6, :2] = 0.0, -0.0, [3.0, 3.0], [3.0, 3.0]
+    for rc in (True, False):
+        assert np.array_equal(o.compute_mask_sorted(p, ref_compat=rc), o.compute_mask(p, ref_compat=rc))
+    dense = np.zeros((1, 4096, 3))                          # every cell occupied -> no vertex-1 artefact
+    dense[0, :, 0], dense[0, :, 1] = np.tile(np.arange(64), 64), np.repeat(np.arange(64), 64)
+    dense[0, :, 2] = np.arange(4096) % 7
+    assert np.array_equal(o.compute_mask_sorted(dense), o.compute_mask(dense))
+    assert (o.compute_mask_sorted(dense) == 1.0).all()
+
+
+def test_streaming_seg_equals_dense_autograd(smpl_model, part_tables):
+    """The non-materialising seg forward + hand-written gradient (the CPU baseline's streaming leg) against the
+    dense restatement under autograd, float64."""
+    import torch
+    from oracle import torch_oracle as to
+    ids, off = part_tables[1]
+    W = 24
+    rng = np.random.default_rng(12)
+    proj = torch.tensor(rng.random((2, 6890, 3)) * (W + 6) - 3, dtype=torch.float64)
+    mask = torch.tensor(np.where(rng.random((2, 6890)) < 0.1, 1.0, 500.0))
+    g = torch.tensor(rng.normal(0, 1, (2, W, W, 32)))
+    pd = proj.clone().requires_grad_(True)
+    dense = to.projects_to_seg(pd, mask, W, ids, off)
+    (dense * g).sum().backward()
+    seg, dproj = to.seg_streaming_fwd_bwd(proj, mask, g, W, ids, off)
+    assert torch.allclose(seg, dense.detach(), rtol=1e-12, atol=1e-300)
+    assert torch.allclose(dproj, pd.grad, rtol=1e-9, atol=1e-14)

@@ -1,0 +1,35 @@
+"""Builds profiles/raster_sq.json: the SQ counters of raster_fwd_kernel (rocprofv3 --pmc passes of `bench.py --mode
+eager`, tools/pmc.sh) + its kernel-trace average duration, from which bench.py derives `roofline.valu_issue_frac` and
+`valu_active_frac`.  Usage:
+    python tools/raster_sq.py <kernel_stats.csv of the eager trace> <issue cycles per VALU instr, from
+           tools/probes/valu_issue_probe> gpurun_out/pmc_TAG_1 [gpurun_out/pmc_TAG_2 ...]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNEL = "raster_fwd_kernel"
+stats, issue = sys.argv[1], float(sys.argv[2])
+us = None
+for r in csv.DictReader(open(stats)):
+    if KERNEL in r["Name"]:
+        us = float(r["AverageNs"]) / 1e3
+acc = collections.defaultdict(list)
+for d in sys.argv[3:]:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {"kernel": KERNEL, "kernel_us": us, "kernel_us_source": os.path.basename(stats), "simds": 1024, "clock_hz": 2.4e9,
+       "clock_note": "nominal peak clock; the clock held under load is lower, so the fractions are lower bounds",
+       "issue_cycles_per_valu": issue,
+       "issue_cycles_source": "tools/probes/valu_issue_probe (profiles/r02_valu_issue_probe.txt), packed and plain fp32 at 4 waves per SIMD",
+       "units": "SQ_INSTS_* = wave-instructions; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* = quad-cycles (x4 = cycles), summed over the chip"}
+for k, v in sorted(acc.items()):
+    out[k] = sum(v) / len(v)
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "raster_sq.json")
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path, {k: out[k] for k in ("kernel_us", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU") if k in out})
