@@ -216,11 +216,17 @@ int smplr_seg_raster(int B, int W, int P, int K, const void *workspace, const fl
  * NaN).  The score is recomputed from the arg-min record, so seg itself is not an input.
  * workspace: smplr_seg_bwd_workspace(B,W) bytes (per-row-block partial sums, merged in order).
  * dproj = NULL stops after the partial sums: the workspace (B, smplr_seg_bwd_nsplit(B,W), 5, 4096, 2) then IS
- * the result, to be handed to smplr_smpl_bwd together with the forward's vslot.                   */
+ * the result, to be handed to smplr_smpl_bwd together with the forward's vslot.
+ * deterministic != 0 (also smplr_silh_bwd): a workgroup's per-vertex sums are accumulated as 64-bit fixed-point
+ * integers (scale = a power of two from max|dseg| and the largest weight, resolution 2^-41 of the largest possible
+ * term) instead of fp32 LDS atomics, whose result depends on arrival order in the last bits: the same inputs then give
+ * the same gradient bit for bit on every launch (the reference's op is a pure function).  Everything downstream
+ * (row-block merge, skinning, blend, pose backward) sums in a fixed order in either mode.             */
 int smplr_seg_bwd_nsplit(int B, int W);
 size_t smplr_seg_bwd_workspace(int B, int W);
 int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
-                  int B, int VP, int W, int P, int K, float *dproj, void *workspace, void *stream);
+                  int B, int VP, int W, int P, int K, float *dproj, void *workspace, int deterministic,
+                  void *stream);
 
 /* ---- projects_to_silhouette: keras_smpl/projects_to_silhouette.py:14-44 ----------------- */
 /* silh (B,W,W,2) = [1-s, s], s = max_v exp(-|proj_v-(c,r)|/1.2) over ALL VP vertices, rows
@@ -229,7 +235,7 @@ size_t smplr_silh_workspace(int B, int VP, int W);
 int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg,
                    void *workspace, void *stream);
 int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg,
-                   const float *proj, int B, int VP, int W, float *dproj, void *stream);
+                   const float *proj, int B, int VP, int W, float *dproj, int deterministic, void *stream);
 
 /* ---- loss head: model.py:119-120 + focal_loss.py:10-46 ----------- */
 /* Reshape(W*W, C) + softmax + categorical_focal_loss fused: logits (npix, C) are the raw

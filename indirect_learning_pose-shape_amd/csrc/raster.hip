@@ -798,6 +798,18 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
   }
 }
 
+// Deterministic form: the run sums are added as 64-bit fixed-point integers (ds_add_u64).  Integer addition is
+// associative, so the slot sums do not depend on the order in which the block's strips reach an accumulator - bit
+// for bit the same result on every launch - and `scale` (a power of two chosen per block from max|dseg| and the
+// largest record weight, see seg_bwd_kernel) keeps 2^-41 of the largest possible term as the resolution, far
+// below an fp32 sum's own rounding.
+__device__ __forceinline__ void seg_flush_det(unsigned long long *acc, int cur, float sx, float sy, float scale) {
+  if (cur >= 0 && (sx != 0.0f || sy != 0.0f)) {
+    atomicAdd(&acc[cur * 2], (unsigned long long)__float2ll_rn(sx * scale));
+    atomicAdd(&acc[cur * 2 + 1], (unsigned long long)__float2ll_rn(sy * scale));
+  }
+}
+
 // One row strip (a 32-lane group, lane = channel) over its W pixels for one slot window.  MW =
 // false is the standard single-window case (no window test per pixel).  The arithmetic is
 // branch-free (a masked pixel contributes kk = 0); the only divergent step is the run boundary.
@@ -805,10 +817,11 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
 // sit at compile-time byte offsets (128 B / 64 B per pixel) from ONE address per lane and batch - the general
 // form spent 29 % of the kernel's vector instructions on 64-bit address arithmetic, in a kernel that is
 // vector-issue bound.
-template <bool MW, bool FAST>
+template <bool MW, bool FAST, bool DET>
 __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, const short *__restrict__ arg,
                                             const float4 *__restrict__ R, int rbytes, float *acc, size_t row0,
-                                            int W, int C, int ch, float fr, int base) {
+                                            int W, int C, int ch, float fr, int base, float scale) {
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
   const int chc = FAST ? ch : min(ch, C - 1);
   const bool chok = ch >= 1 && ch < C;
   const __amdgpu_buffer_rsrc_t rrs =
@@ -863,7 +876,8 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       const bool on = a[u] >= 0 && d2 > 0.0f && k != 0.0f;
       const float kk = on ? k * __builtin_amdgcn_rcpf(d2) : 0.0f;
       if (on && a[u] != cur) {
-        seg_flush(acc, cur, sx, sy);
+        if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+        else seg_flush(acc, cur, sx, sy);
         cur = a[u];
         sx = 0.0f;
         sy = 0.0f;
@@ -872,15 +886,20 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       sy = fmaf(kk, dv, sy);
     }
   }
-  seg_flush(acc, cur, sx, sy);
+  if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+  else seg_flush(acc, cur, sx, sy);
 }
 
+template <bool DET>
 __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *__restrict__ dseg,
                                                       const short *__restrict__ arg,
                                                       const float4 *__restrict__ rec, int S, int VP, int W,
                                                       int P, float *__restrict__ dproj,
                                                       float *__restrict__ part, int rows) {
-  __shared__ float acc[SB_SLOTS * 2];
+  // SB_SLOTS x 2 accumulators: fp32 (32 KB), or 64-bit fixed point in the deterministic form (64 KB)
+  extern __shared__ __attribute__((aligned(16))) float acc[];
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+  __shared__ unsigned s_gmax, s_m2max;
   const int n = blockIdx.y, tid = threadIdx.x, nthr = 32 * rows;   // a 32-lane group per row of the block
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
@@ -896,22 +915,48 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
   const int ro = blockIdx.x * rows + strip;            // output (flipped) row of this strip
   const float fr = (float)(W - 1 - ro);
   const size_t row0 = (size_t)n * npix + (size_t)ro * W;
+  float scale = 1.0f, inv_scale = 1.0f;
+  if (DET) {
+    // Bound of one term: |g - g0| m |du| / d <= 2 max|dseg| max(m); a slot collects at most rows x W of them.
+    // max is order-independent, so the scale itself is reproducible.  (bit patterns of non-negative floats order
+    // like the floats; a NaN / inf cotangent gives a NaN / inf bound and garbage either way)
+    if (tid == 0) { s_gmax = 0u; s_m2max = 0u; }
+    __syncthreads();
+    unsigned gm = 0u, mm = 0u;
+    if (ro < W)
+      for (int i = ch; i < W * C; i += 32) gm = max(gm, __float_as_uint(fabsf(dseg[row0 * C + i])));
+    for (int i = tid; i < nslots; i += nthr) mm = max(mm, __float_as_uint(fabsf(R[i].z)));
+    atomicMax(&s_gmax, gm);
+    atomicMax(&s_m2max, mm);
+    __syncthreads();
+    int eg, em;
+    frexpf(__uint_as_float(s_gmax), &eg);                      // max|g| < 2^eg
+    frexpf(fmaxf(__uint_as_float(s_m2max), 1.0f), &em);        // max m^2 < 2^em -> max m < 2^((em + 1) / 2)
+    int terms = 1;
+    while ((1 << terms) < rows * W) ++terms;                   // rows x W <= 2^terms
+    // |sum| < 2^(1 + eg + (em + 1) / 2 + terms) must stay below 2^62
+    const int e = min(max(60 - eg - (em + 1) / 2 - terms, -100), 100);
+    scale = ldexpf(1.0f, e);
+    inv_scale = ldexpf(1.0f, -e);
+  }
   const int nwin = (nslots + SB_SLOTS - 1) / SB_SLOTS;    // 1 in the standard pipeline
   for (int win = 0; win < nwin; ++win) {
     const int base = win * SB_SLOTS;
     const int nsl = min(nslots - base, SB_SLOTS);
     if (win > 0) __syncthreads();
-    for (int i = tid; i < nsl * 2; i += nthr) acc[i] = 0.0f;
+    if (DET) for (int i = tid; i < nsl * 2; i += nthr) acc64[i] = 0ull;
+    else for (int i = tid; i < nsl * 2; i += nthr) acc[i] = 0.0f;
     __syncthreads();
     if (ro < W) {
       const bool fast = C == 32 && W % SB_U == 0;           // block-uniform
-      if (nwin == 1 && fast) seg_bwd_row<false, true>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0);
-      else if (nwin == 1) seg_bwd_row<false, false>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0);
-      else seg_bwd_row<true, false>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, base);
+      if (nwin == 1 && fast) seg_bwd_row<false, true, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale);
+      else if (nwin == 1) seg_bwd_row<false, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale);
+      else seg_bwd_row<true, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale);
     }
     __syncthreads();
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
-    for (int i = tid; i < nsl * 2; i += nthr) dst[i] = acc[i];
+    if (DET) for (int i = tid; i < nsl * 2; i += nthr) dst[i] = (float)(long long)acc64[i] * inv_scale;
+    else for (int i = tid; i < nsl * 2; i += nthr) dst[i] = acc[i];
   }
 }
 
@@ -1239,16 +1284,323 @@ __global__ __launch_bounds__(SF_T) void silh_fused_kernel(const float *__restric
 #undef SMPLR_SILH_VERTEX
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pruned silhouette forward, one LANE per pixel, candidates shared by the 64 pixels of a wave's 8 x 8 tile (cell
+// windows of at most 64 columns: W <= 48, the reference's silhouette size, train_stage2_silhouette.py:349-354).
+// Same binning and the same exact pruning idea as silh_fused_kernel, re-cut around what the counters showed: that
+// kernel issued 18.6 M vector wave-instructions at B = 128 - more than the whole 31-part rasteriser - in nested
+// per-lane loops over rows, cells and vertices (profiles/r02_silh_*).  Here:
+//  (0) binning also leaves, per pixel of the image, the vertex of the pixel's OWN cell nearest to it (a pixel centre
+//      is its cell's centre: one 64-bit LDS atomic min per vertex, order-independent), and per row of the cell
+//      grid the signed offset from every column to the row's nearest occupied cell (one byte per cell);
+//  (1) a pixel whose own cell is occupied starts from that vertex at distance d <= 0.7072 - and is done unless
+//      d > 0.5, since every other cell's square lies at least half a cell away;
+//  (2) any other pixel walks the rows outwards from its own: nearest occupied cell q0 at squared centre distance
+//      D2 = min(off^2 + k^2), one byte read per row, until k^2 > (sqrt(D2) + 1.4143)^2, keeping as bits of one word
+//      the rows that hold a cell within that bound; the first vertex of q0 gives a real distance d <= sqrt(D2) + 0.7072;
+//  (3) a vertex of cell (x, y) lies within half a cell of its centre, so it is at least hypot(max(|x - cx| - 0.5, 0),
+//      max(|y - cy| - 0.5, 0)) from the pixel: only cells whose square comes within d can hold the nearest vertex.
+//      Those are few (about three sparse cells of the outline per exterior pixel) and nearly the same for
+//      neighbouring pixels, so the lanes OR their candidate cells into a 64 x 64-bit map in LDS (one word per cell
+//      row, owned by the wave), lane y then takes row y's word and looks up the record range of its first run of
+//      cells, and EVERY lane evaluates every record of every run - wave-uniform loops over ranges handed round by
+//      v_readlane, broadcast LDS reads, no per-lane walks; an extra candidate can only lower a lane's minimum
+//      towards the truth.
+// Keys are (d^2 bits, vertex index) compared as 64-bit integers, exactly as in silh_fused_kernel: the same d^2
+// expression, ties to the lowest vertex index - the two kernels give bit-identical outputs.
+constexpr int SPX_TILE = 8;      // 8 x 8 pixels per wave
+constexpr int SPX_EMPTY = 127;   // offset-table entry of an empty row
+
+// LDS (bytes): cell starts | offset table | row words | own-cell keys | per-wave candidate maps | records.
+// Cell rows have a stride of GW + 1 and the own-cell rows of W + 1: vertices that follow each other in the mesh sit
+// above each other as often as side by side, and a stride of 64 words put all of those on one bank.
+struct SpxLds { size_t gtab, rowmask, own, ubm, rec, total; int GWP, WP; };
+static SpxLds silh_px_layout(int VP, int W) {
+  SpxLds L;
+  const int GW = W + 2 * SM;
+  L.GWP = GW + 1;
+  L.WP = W + 1;
+  size_t off = (size_t)((GW * L.GWP + 4) & ~3) * 4;
+  L.gtab = off;     off += (size_t)((GW * L.GWP + 15) & ~15);
+  L.rowmask = off;  off += (size_t)((GW + 1) & ~1) * 8;
+  L.own = off;      off += (size_t)W * L.WP * 8;
+  L.ubm = off;      off += (size_t)(SF_T / 64) * 64 * 8;
+  off = (off + 15) & ~(size_t)15;
+  L.rec = off;      off += (size_t)VP * 16;
+  L.total = off;
+  return L;
+}
+
+__global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__ proj, int VP, int W, SpxLds L,
+                                                       float *__restrict__ out, int *__restrict__ arg_out) {
+  extern __shared__ __attribute__((aligned(16))) int s_cnt[];
+  __shared__ int s_next_tile;
+  if (threadIdx.x == 0) s_next_tile = 0;             // (ordered by the binning's barriers)
+  __shared__ int s_wave[SF_T / 64];
+  __shared__ int s_nout;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int GW = W + 2 * SM, GWP = L.GWP, WP = L.WP, cells = GW * GWP;        // GW <= 64
+  char *lds = reinterpret_cast<char *>(s_cnt);
+  signed char *gtab = reinterpret_cast<signed char *>(lds + L.gtab);
+  unsigned long long *rowmask = reinterpret_cast<unsigned long long *>(lds + L.rowmask);
+  unsigned long long *own = reinterpret_cast<unsigned long long *>(lds + L.own);
+  unsigned long long *ubm = reinterpret_cast<unsigned long long *>(lds + L.ubm) + (tid >> 6) * 64;
+  float4 *sRec = reinterpret_cast<float4 *>(lds + L.rec);
+  const float *pj = proj + (size_t)n * VP * 3;
+  // ---- binning: every vertex requested up front
+  float pu[IPT_MAX], pv[IPT_MAX];
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int v = min(tid + j * SF_T, VP - 1);
+    pu[j] = pj[v * 3];
+    pv[j] = pj[v * 3 + 1];
+  }
+  for (int i = tid; i <= cells; i += SF_T) s_cnt[i] = 0;
+  for (int i = tid; i < W * WP; i += SF_T) own[i] = ~0ull;
+  if (tid < GW) rowmask[tid] = 0ull;
+  if (tid == 0) s_nout = 0;
+  __syncthreads();
+  int pc[IPT_MAX], rank[IPT_MAX];
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int v = tid + j * SF_T;
+    pc[j] = -2;                                  // no vertex
+    rank[j] = 0;
+    if (v < VP) {
+      const float ru = rintf(pu[j]), rv = rintf(pv[j]);
+      const float cx = ru + (float)SM, cy = rv + (float)SM;
+      if (cx >= 0.0f && cx < (float)GW && cy >= 0.0f && cy < (float)GW) {
+        pc[j] = (int)cy * GWP + (int)cx;
+        rank[j] = atomicAdd(&s_cnt[pc[j]], 1);              // arrival order within the cell
+        if (ru >= 0.0f && ru < (float)W && rv >= 0.0f && rv < (float)W) {
+          // the pixel at this cell's centre: its key for this vertex, as the pixel itself would compute it
+          const float du = pu[j] - ru, dv = pv[j] - rv;
+          atomicMin(&own[(int)rv * WP + (int)ru],
+                    ((unsigned long long)__float_as_uint(fmaf(du, du, dv * dv)) << 32) | (unsigned int)v);
+        }
+      } else {
+        pc[j] = -1;                              // outlier (also NaN positions)
+        rank[j] = atomicAdd(&s_nout, 1);
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the counts: s_cnt[e] = start of cell e, s_cnt[cells] = vertices inside the window;
+  // the occupied cells set their bit of the row words
+  const int ept = (cells + SF_T - 1) / SF_T;
+  const int e0 = tid * ept, e1 = min(cells, e0 + ept);
+  int lc = 0;
+  for (int e = e0; e < e1; ++e) {
+    const int c = s_cnt[e];
+    lc += c;
+    if (c) {
+      const int y = e / GWP;
+      atomicOr(&rowmask[y], 1ull << (e - y * GWP));
+    }
+  }
+  int tot_v;
+  int run_v = block_excl_scan(lc, s_wave, &tot_v);          // (its barriers also publish the row words)
+  for (int e = e0; e < e1; ++e) {
+    const int c = s_cnt[e];
+    s_cnt[e] = run_v;
+    run_v += c;
+  }
+  if (tid == 0) s_cnt[cells] = tot_v;
+  const int nout = s_nout;
+  // offsets to the nearest occupied cell of each row (the pad column is never read)
+  for (int e = tid; e < GW * GW; e += SF_T) {
+    const int y = e / GW, x = e - y * GW;
+    const unsigned long long m = rowmask[y];
+    gtab[y * GWP + x] = (signed char)(m ? nearest_bit1(m, x) : SPX_EMPTY);
+  }
+  __syncthreads();
+  // placement by rank
+#pragma unroll
+  for (int j = 0; j < IPT_MAX; ++j) {
+    const int v = tid + j * SF_T;
+    int dst = -1;
+    if (pc[j] >= 0) dst = s_cnt[pc[j]] + rank[j];
+    else if (pc[j] == -1) dst = tot_v + rank[j];
+    if (dst >= 0) sRec[dst] = make_float4(pu[j], pv[j], __int_as_float(v), 0.0f);
+  }
+  __syncthreads();
+  // ---- pixels: a wave takes 8 x 8 tiles, handed out through a counter (tiles on the outline cost more)
+  const int lane = tid & 63;
+  const int tpr = (W + SPX_TILE - 1) / SPX_TILE, ntile = tpr * tpr;
+  const int nloc = (ntile - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+#define SMPLR_SPX_KEY(rec_)                                                                               \
+  (((unsigned long long)__float_as_uint(fmaf((rec_).x - fc, (rec_).x - fc, ((rec_).y - fr) * ((rec_).y - fr))) << 32) | \
+   (unsigned int)__float_as_int((rec_).z))
+  // records [i0_, i1_) (wave-uniform, i0_ < i1_) against every lane's pixel: four broadcast reads in flight per
+  // step; a step's surplus slots repeat the range's last record (the same key again: harmless)
+#define SMPLR_SPX_RANGE(i0_, i1_)                                                                         \
+  for (int i_ = (i0_); i_ < (i1_); i_ += 4) {                                                             \
+    const int l_ = (i1_) - 1;                                                                             \
+    const float4 ra_ = sRec[i_], rb_ = sRec[min(i_ + 1, l_)], rc_ = sRec[min(i_ + 2, l_)], rd_ = sRec[min(i_ + 3, l_)]; \
+    const unsigned long long ka_ = SMPLR_SPX_KEY(ra_), kb_ = SMPLR_SPX_KEY(rb_), kc_ = SMPLR_SPX_KEY(rc_), kd_ = SMPLR_SPX_KEY(rd_); \
+    const unsigned long long kab_ = ka_ < kb_ ? ka_ : kb_, kcd_ = kc_ < kd_ ? kc_ : kd_;                  \
+    const unsigned long long k4_ = kab_ < kcd_ ? kab_ : kcd_;                                             \
+    best = k4_ < best ? k4_ : best;                                                                       \
+  }
+  for (;;) {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(&s_next_tile, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+#ifdef SPX_SKIPPIX
+    break;
+#endif
+    if (t >= nloc) break;
+    const int tile = t * (int)gridDim.y + (int)blockIdx.y;
+    const int ty = tile / tpr, tx = tile - ty * tpr;
+    const int r_ = ty * SPX_TILE + (lane >> 3), c_ = tx * SPX_TILE + (lane & 7);
+    const bool live = r_ < W && c_ < W;
+    const int r = min(r_, W - 1), c = min(c_, W - 1);      // clamped lanes repeat a border pixel
+    const float fc = (float)c, fr = (float)r;
+    const int cx = c + SM, cy = r + SM;
+    // this wave's candidate map, one word per cell row.  The lanes talk to each other through it, so every access
+    // is an atomic operation to the compiler (with plain accesses it forwards a lane's own zero to its read)
+    __hip_atomic_store(&ubm[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    unsigned long long best = own[r * WP + c];             // (d^2 bits << 32) | vertex index; ~0: own cell empty
+    unsigned long long rows = 0ull;
+    float lim = -1.0f;                                      // squared search radius (< 0: nothing to search)
+    if (best != ~0ull) {
+      // (1) own cell occupied: other cells matter only if the nearest own vertex is farther than half a cell
+      const float d2 = __uint_as_float((unsigned int)(best >> 32));
+      if (d2 > 0.25f) {
+        lim = d2 * 1.000001f;
+        rows = 7ull << (cy - 1);                            // rows cy - 1 .. cy + 1 (cy >= SM)
+      }
+    } else {
+      // (2) nearest occupied cell + the rows that can hold a candidate
+      int best2 = 1 << 30, q0 = -1;
+      float bound = INFINITY;
+      const signed char *gcol = gtab + cx;
+      for (int k = 0; k < GW; ++k) {
+        const int kk = k * k;
+        if ((float)kk > bound) break;
+#pragma unroll
+        for (int sgn = 0; sgn < 2; ++sgn) {
+          const int y = sgn ? cy - k : cy + k;
+          if (y < 0 || y >= GW || (sgn && k == 0)) continue;
+          const int off = gcol[y * GWP];
+          if (off == SPX_EMPTY) continue;
+          const int d2 = off * off + kk;
+          if (d2 < best2) {
+            best2 = d2;
+            q0 = y * GWP + cx + off;
+            const float rr = __builtin_amdgcn_sqrtf((float)d2) + 1.4143f;
+            bound = rr * rr * 1.0001f;
+          }
+          if ((float)d2 <= bound) rows |= 1ull << y;
+        }
+      }
+      if (q0 >= 0) {
+        const float4 r0 = sRec[s_cnt[q0]];                  // any vertex of q0: an upper bound of the answer
+        best = SMPLR_SPX_KEY(r0);
+        lim = __uint_as_float((unsigned int)(best >> 32)) * 1.000001f;
+      } else {
+        rows = 0ull;
+      }
+    }
+#ifdef SPX_SKIP3
+    rows = 0ull;
+#endif
+    // (3) A cell (x, y) is a candidate iff max(|x - cx| - 0.5, 0)^2 + max(|y - cy| - 0.5, 0)^2 <= lim, i.e. row by
+    // row |y - cy| <= 0.5 + sqrt(lim) and |x - cx| <= 0.5 + sqrt(lim - dym^2) (1e-4 covers the approximate roots)
+    if (lim >= 0.0f) {
+      const int yr = (int)(__builtin_amdgcn_sqrtf(lim) + 0.5001f);
+      const int ylo = max(0, cy - yr), yhi = min(GW - 1, cy + yr);
+      unsigned long long keep = ~((1ull << ylo) - 1ull);
+      if (yhi < 63) keep &= (2ull << yhi) - 1ull;
+      rows &= keep;
+    } else {
+      rows = 0ull;
+    }
+    while (rows) {                                          // this lane's rows: its candidate cells into the wave's map
+      const int y = __ffsll((long long)rows) - 1;
+      rows &= rows - 1ull;
+      const float dym = fmaxf((float)abs(y - cy) - 0.5f, 0.0f);
+      const float rem = lim - dym * dym;
+      if (rem < 0.0f) continue;
+      const int w = (int)(__builtin_amdgcn_sqrtf(rem) + 0.5001f);
+      const int xlo = max(0, cx - w), xhi = min(GW - 1, cx + w);
+      unsigned long long m = rowmask[y] & ~((1ull << xlo) - 1ull);
+      if (xhi < 63) m &= (2ull << xhi) - 1ull;
+      if (m) atomicOr(&ubm[y], m);
+    }
+    // LDS operations of one wave execute in order: the map is complete when lane y reads row y's word
+    unsigned long long um = __hip_atomic_load(&ubm[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    while (__ballot(um != 0ull)) {
+      // lane y: the first run of consecutive candidate cells of row y = one contiguous range of records
+      int i0 = 0, i1 = 0;
+      if (um) {
+        const int x0 = __ffsll((long long)um) - 1;
+        const unsigned long long inv = ~(um >> x0);
+        const int len = inv ? __ffsll((long long)inv) - 1 : 64 - x0;
+        um = (x0 + len >= 64) ? 0ull : (um >> (x0 + len)) << (x0 + len);
+        const int e = lane * GWP + x0;
+        i0 = s_cnt[e];
+        i1 = s_cnt[e + len];
+      }
+      unsigned long long todo = __ballot(i1 > i0);
+      while (todo) {                                        // wave-uniform: every lane evaluates every range
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int a0 = __builtin_amdgcn_readlane(i0, l), a1 = __builtin_amdgcn_readlane(i1, l);
+        SMPLR_SPX_RANGE(a0, a1)
+      }
+    }
+    if (nout > 0) SMPLR_SPX_RANGE(tot_v, tot_v + nout)       // outliers: always
+    if (live) {
+      float score = 0.0f;
+      int pos = -1;
+      if (best != ~0ull) {
+        score = expf(-sqrtf(__uint_as_float((unsigned int)(best >> 32))) / 1.2f);
+        pos = (int)(best & 0xffffffffull);
+      }
+      const size_t o = ((size_t)n * W + (W - 1 - r)) * W + c;   // rows flipped (:42)
+      *reinterpret_cast<float2 *>(out + o * 2) = make_float2(1.0f - score, score);
+      arg_out[o] = pos;
+    }
+  }
+#undef SMPLR_SPX_RANGE
+#undef SMPLR_SPX_KEY
+}
+
+// DET: the per-vertex sums as 64-bit fixed point (see seg_flush_det): bit-reproducible whatever the order in which
+// the 1 024 threads' pixels reach a vertex' accumulator.
+template <bool DET>
 __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict__ dsilh,
                                                         const float *__restrict__ silh,
                                                         const int *__restrict__ arg,
                                                         const float *__restrict__ proj, int VP, int W,
                                                         float *__restrict__ dproj) {
   extern __shared__ __attribute__((aligned(16))) float acc[];
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+  __shared__ unsigned s_gmax;
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < VP * 2; i += 1024) acc[i] = 0.0f;
+  if (DET) {
+    for (int i = tid; i < VP * 2; i += 1024) acc64[i] = 0ull;
+    if (tid == 0) s_gmax = 0u;
+  } else {
+    for (int i = tid; i < VP * 2; i += 1024) acc[i] = 0.0f;
+  }
   __syncthreads();
   const int npix = W * W;
+  float scale = 1.0f, inv_scale = 1.0f;
+  if (DET) {
+    unsigned gm = 0u;
+    for (int i = tid; i < npix * 2; i += 1024) gm = max(gm, __float_as_uint(fabsf(dsilh[(size_t)n * npix * 2 + i])));
+    atomicMax(&s_gmax, gm);
+    __syncthreads();
+    int eg, terms = 1;
+    frexpf(__uint_as_float(s_gmax), &eg);
+    while ((1 << terms) < npix) ++terms;
+    // a term is |g1 - g0| s / 1.2 |du| / d < 2^(1 + eg); a vertex collects at most W^2 <= 2^terms of them
+    const int e = min(max(60 - eg - terms, -100), 100);
+    scale = ldexpf(1.0f, e);
+    inv_scale = ldexpf(1.0f, -e);
+  }
   const float *pj = proj + (size_t)n * VP * 3;
   for (int o = tid; o < npix; o += 1024) {
     const size_t po = (size_t)n * npix + o;
@@ -1263,15 +1615,21 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
     const float k = -g * sc / 1.2f;
     if (d > 0.0f && k != 0.0f) {
       const float kk = k / d;
-      atomicAdd(&acc[v * 2], kk * du);
-      atomicAdd(&acc[v * 2 + 1], kk * dv);
+      if (DET) {
+        atomicAdd(&acc64[v * 2], (unsigned long long)__float2ll_rn(kk * du * scale));
+        atomicAdd(&acc64[v * 2 + 1], (unsigned long long)__float2ll_rn(kk * dv * scale));
+      } else {
+        atomicAdd(&acc[v * 2], kk * du);
+        atomicAdd(&acc[v * 2 + 1], kk * dv);
+      }
     }
   }
   __syncthreads();
   float *o = dproj + (size_t)n * VP * 3;
   for (int i = tid; i < VP * 3; i += 1024) {
     const int v = i / 3, c = i - v * 3;
-    o[i] = (c < 2) ? acc[v * 2 + c] : 0.0f;
+    if (DET) o[i] = (c < 2) ? (float)(long long)acc64[v * 2 + c] * inv_scale : 0.0f;
+    else o[i] = (c < 2) ? acc[v * 2 + c] : 0.0f;
   }
 }
 
@@ -1430,7 +1788,7 @@ size_t smplr_seg_bwd_workspace(int B, int W) {
 }
 
 int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B, int VP, int W, int P, int K,
-                  float *dproj, void *workspace, void *stream) {
+                  float *dproj, void *workspace, int deterministic, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= 16000,
                 "smplr_seg_bwd: bad sizes B=%d VP=%d W=%d P=%d K=%d", B, VP, W, P, K);
@@ -1440,8 +1798,18 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B
   const int rows = seg_bwd_rows(B, W), nsplit = (W + rows - 1) / rows;
   const int S = seg_slots(P, K);
   SMPLR_REQUIRE(S <= SB_NWIN * SB_SLOTS, "smplr_seg_bwd: %d record slots exceed %d", S, SB_NWIN * SB_SLOTS);
-  hipLaunchKernelGGL(seg_bwd_kernel, dim3(nsplit, B), dim3(32 * rows), 0, st, dseg, reinterpret_cast<const short *>(arg),
-                     reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, reinterpret_cast<float *>(workspace), rows);
+  if (deterministic) {
+    const size_t lds = (size_t)SB_SLOTS * 2 * sizeof(unsigned long long);
+    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_bwd_kernel<true>, dim3(nsplit, B), dim3(32 * rows), lds, st, dseg,
+                       reinterpret_cast<const short *>(arg), reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj,
+                       reinterpret_cast<float *>(workspace), rows);
+  } else {
+    hipLaunchKernelGGL(seg_bwd_kernel<false>, dim3(nsplit, B), dim3(32 * rows), (size_t)SB_SLOTS * 2 * sizeof(float), st,
+                       dseg, reinterpret_cast<const short *>(arg), reinterpret_cast<const float4 *>(rec), S, VP, W, P,
+                       dproj, reinterpret_cast<float *>(workspace), rows);
+  }
   SMPLR_LAUNCH_CHECK("smplr_seg_bwd");
   if (!dproj) return 0;                        // slot sums only: smplr_smpl_bwd gathers them by vertex
   hipLaunchKernelGGL(seg_bwd_merge_kernel, dim3(SB_SLOTS / 256, B), dim3(256), 0, st,
@@ -1464,6 +1832,15 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
   if (B == 0) return 0;
   SMPLR_REQUIRE(proj && silh && arg && workspace, "smplr_silh_fwd: null pointer");
   hipStream_t st = as_stream(stream);
+  if (W + 2 * SM <= 64 && VP <= SF_T * IPT_MAX && silh_px_layout(VP, W).total <= 159 * 1024) {
+    const SpxLds L = silh_px_layout(VP, W);
+    const int nsplit = B >= 256 ? 1 : (B >= 128 ? 2 : 4);      // one workgroup per CU (256 CUs)
+    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_px_kernel), L.total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(silh_px_kernel, dim3(B, nsplit), dim3(SF_T), L.total, st, proj, VP, W, L, silh, arg);
+    SMPLR_LAUNCH_CHECK("smplr_silh_fwd");
+    return 0;
+  }
   if (W <= SILH_WMAX && VP <= SF_T * IPT_MAX && silh_fused_lds(VP, W) <= 150 * 1024) {
     const size_t lds = silh_fused_lds(VP, W);
     const int nsplit = B >= 256 ? 1 : (B >= 128 ? 2 : 4);      // one workgroup per CU (256 CUs)
@@ -1490,17 +1867,24 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
 }
 
 int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg, const float *proj, int B,
-                   int VP, int W, float *dproj, void *stream) {
+                   int VP, int W, float *dproj, int deterministic, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && VP > 0 && W > 0 && W <= 1024, "smplr_silh_bwd: bad sizes B=%d VP=%d W=%d", B, VP, W);
   if (B == 0) return 0;
   SMPLR_REQUIRE(dsilh && silh && arg && proj && dproj, "smplr_silh_bwd: null pointer");
-  const size_t lds = (size_t)VP * 2 * sizeof(float);
+  const size_t lds = (size_t)VP * 2 * (deterministic ? sizeof(unsigned long long) : sizeof(float));
   SMPLR_REQUIRE(lds <= 150 * 1024, "smplr_silh_bwd: VP=%d needs %zu B of LDS", VP, lds);
-  int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel), lds);
-  if (rc) return rc;
-  hipLaunchKernelGGL(silh_bwd_kernel, dim3(B), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj, VP,
-                     W, dproj);
+  if (deterministic) {
+    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel<true>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(silh_bwd_kernel<true>, dim3(B), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj, VP,
+                       W, dproj);
+  } else {
+    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel<false>), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(silh_bwd_kernel<false>, dim3(B), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj, VP,
+                       W, dproj);
+  }
   SMPLR_LAUNCH_CHECK("smplr_silh_bwd");
   return 0;
 }

@@ -17,7 +17,7 @@ from .keras_smpl.batch_smpl import _resolve_model
 
 class SMPLDecoder(nn.Module):
     def __init__(self, smpl_path=None, img_wh=48, vertex_sampling=None, num_cam=4, grid_wh=64,
-                 ref_compat=True, with_silhouette=False, streams=1, silh_wh=None):
+                 ref_compat=True, with_silhouette=False, streams=1, silh_wh=None, deterministic=False):
         super().__init__()
         self._model = _resolve_model(smpl_path)
         self.img_wh = int(img_wh)
@@ -30,6 +30,10 @@ class SMPLDecoder(nn.Module):
         # the silhouette may have its own resolution (train_stage2_silhouette.py:72-86: `silhs_output_wh`)
         self.silh_wh = int(silh_wh) if silh_wh is not None else self.img_wh
         self.streams = int(streams)      # concurrent mesh chunks (HIP streams); results do not depend on it
+        # deterministic=True: the rasterisers' backward accumulates in 64-bit fixed point instead of fp32 LDS atomics,
+        # so the same inputs give the same gradient bit for bit on every launch (the reference's ops are pure functions;
+        # the default's gradients repeat to rounding).  Forward outputs are bit-reproducible in either mode.
+        self.deterministic = bool(deterministic)
         self._consts = None
         self._dev = None
 
@@ -47,7 +51,8 @@ class SMPLDecoder(nn.Module):
         pt = ops.get_part_table(self.vs, x.device, c.V)
         verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(
             x, c, self.num_cam, self.img_wh, self.vs, pt, self.grid_wh, self.ref_compat,
-            (True if self.silh_wh == self.img_wh else self.silh_wh) if self.with_silhouette else False, self.streams)
+            (True if self.silh_wh == self.img_wh else self.silh_wh) if self.with_silhouette else False, self.streams,
+            self.deterministic)
         out = dict(verts=verts, projects=proj, mask=mask, seg=seg, J_transformed=jt)
         if self.with_silhouette:
             out["silhouette"] = silh

@@ -336,7 +336,7 @@ def _seg_raster(ws, rec, B, W, pt: PartTable, out=None):
 
 
 @on_device
-def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True):
+def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True, deterministic=False):
     """merge=True -> dproj (B,VP,3).  merge=False -> (part, nsplit): the per-row-block slot sums, to be handed
     to _smpl_bwd(seg_grad=(part, vslot, nsplit)) which gathers them by vertex (no merge launch, no dproj)."""
     lib = _lib.load()
@@ -344,7 +344,7 @@ def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True):
     ws = _workspace(lib.smplr_seg_bwd_workspace(B, W), dseg)
     dproj = _empty((B, VP, 3), dseg) if merge else None
     check(lib.smplr_seg_bwd(ptr(dseg), ptr(arg), ptr(rec), B, VP, W, pt.P, pt.K, ptr(dproj), ptr(ws),
-                            stream()), "smplr_seg_bwd")
+                            1 if deterministic else 0, stream()), "smplr_seg_bwd")
     return dproj if merge else (ws, int(lib.smplr_seg_bwd_nsplit(B, W)))
 
 
@@ -373,12 +373,12 @@ def _silh_fwd(proj, W, out=None):
 
 
 @on_device
-def _silh_bwd(dsilh, silh, arg, proj, W):
+def _silh_bwd(dsilh, silh, arg, proj, W, deterministic=False):
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
     dproj = _empty((B, VP, 3), proj)
-    check(lib.smplr_silh_bwd(ptr(dsilh), ptr(silh), ptr(arg), ptr(proj), B, VP, W, ptr(dproj), stream()),
-          "smplr_silh_bwd")
+    check(lib.smplr_silh_bwd(ptr(dsilh), ptr(silh), ptr(arg), ptr(proj), B, VP, W, ptr(dproj),
+                             1 if deterministic else 0, stream()), "smplr_silh_bwd")
     return dproj
 
 
@@ -449,12 +449,12 @@ class SegRasterFn(torch.autograd.Function):
 
     @staticmethod
     @on_device
-    def forward(ctx, proj, mask, img_wh: int, pt: PartTable):
+    def forward(ctx, proj, mask, img_wh: int, pt: PartTable, deterministic=False):
         proj = require_cuda(proj, "projects_with_depth")
         mask = require_cuda(mask, "mask_vals")
         ctx.set_materialize_grads(False)
         seg, arg, rec = _seg_fwd(proj, mask, int(img_wh), pt)
-        ctx.W, ctx.pt, ctx.VP = int(img_wh), pt, proj.shape[1]
+        ctx.W, ctx.pt, ctx.VP, ctx.det = int(img_wh), pt, proj.shape[1], bool(deterministic)
         ctx.save_for_backward(arg, rec)
         ctx.mark_non_differentiable(arg, rec)
         return seg, arg, rec
@@ -464,9 +464,9 @@ class SegRasterFn(torch.autograd.Function):
     def backward(ctx, dseg, _darg, _drec):
         arg, rec = ctx.saved_tensors
         if dseg is None:
-            return None, None, None, None
+            return None, None, None, None, None
         dseg = require_cuda(dseg, "dseg")
-        return _seg_bwd(dseg, arg, rec, ctx.VP, ctx.W, ctx.pt), None, None, None
+        return _seg_bwd(dseg, arg, rec, ctx.VP, ctx.W, ctx.pt, deterministic=ctx.det), None, None, None, None
 
 
 class SilhRasterFn(torch.autograd.Function):
@@ -474,10 +474,10 @@ class SilhRasterFn(torch.autograd.Function):
 
     @staticmethod
     @on_device
-    def forward(ctx, proj, img_wh: int):
+    def forward(ctx, proj, img_wh: int, deterministic=False):
         proj = require_cuda(proj, "projects_with_depth")
         silh, arg = _silh_fwd(proj, int(img_wh))
-        ctx.W = int(img_wh)
+        ctx.W, ctx.det = int(img_wh), bool(deterministic)
         ctx.save_for_backward(proj, silh, arg)
         ctx.mark_non_differentiable(arg)
         return silh, arg
@@ -487,7 +487,7 @@ class SilhRasterFn(torch.autograd.Function):
     def backward(ctx, dsilh, _darg):
         proj, silh, arg = ctx.saved_tensors
         dsilh = require_cuda(dsilh, "dsilh")
-        return _silh_bwd(dsilh, silh, arg, proj, ctx.W), None
+        return _silh_bwd(dsilh, silh, arg, proj, ctx.W, ctx.det), None, None
 
 
 def _focal_targets(target, npix, C):
@@ -763,7 +763,7 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     @on_device
     def forward(ctx, x, consts: SMPLConstants, num_cam, img_wh, vertex_sampling, pt: PartTable,
-                grid_wh, ref_compat, with_silh, nchunk=1):
+                grid_wh, ref_compat, with_silh, nchunk=1, deterministic=False):
         x = require_cuda(x, "x")
         ctx.set_materialize_grads(False)
         lib = _lib.load()
@@ -800,6 +800,7 @@ class DecoderFn(torch.autograd.Function):
             _run_chunks(bounds, x.device, run)
         ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, bool(with_silh)
         ctx.Ws = Ws
+        ctx.det = bool(deterministic)
         ctx.bounds = bounds
         ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot)
         ctx.mark_non_differentiable(mask)
@@ -821,10 +822,11 @@ class DecoderFn(torch.autograd.Function):
             dproj, seg_grad = None, None
             if dseg is not None:
                 # the slot sums stay in the workspace; the skinning backward gathers them by vertex
-                part, nsplit = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt, merge=False)
+                part, nsplit = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt, merge=False,
+                                        deterministic=ctx.det)
                 seg_grad = (part, vslot[lo:hi], nsplit)
             if dsilh is not None:
-                d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.Ws)
+                d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.Ws, ctx.det)
                 dproj = d2 if dproj is None else dproj + d2
             if dproj_in is not None:
                 dproj = dproj_in[lo:hi] if dproj is None else dproj + dproj_in[lo:hi]
@@ -836,4 +838,4 @@ class DecoderFn(torch.autograd.Function):
 
         if x.shape[0] > 0:
             _run_chunks(ctx.bounds, x.device, run)
-        return (dx,) + (None,) * 9
+        return (dx,) + (None,) * 10

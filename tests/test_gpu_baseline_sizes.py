@@ -205,3 +205,72 @@ def test_ops_follow_their_operands_device(smpl_model):
         res.append((out["verts"].detach().cpu(), out["seg"].detach().cpu(), xg.grad.cpu()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     grad_close(res[1][2].numpy(), res[0][2].numpy(), 1e-5, "dx cuda:1 vs cuda:0")
+
+
+@pytest.mark.parametrize("with_silh", [False, True])
+def test_deterministic_backward_is_bit_reproducible_B128(smpl_model, with_silh):
+    """SMPLDecoder(deterministic=True) at B = 128 (race row: the reference's ops are pure functions):
+    five runs of the same step give torch.equal gradients - the rasterisers' backward accumulates in 64-bit fixed
+    point instead of fp32 LDS atomics - and that gradient agrees with the default mode's to fp32 rounding."""
+    from ilps_amd.decoder import SMPLDecoder
+    W, B = 48, 128
+    x = t(make_x(B, W, seed=2024))
+    rng = np.random.default_rng(6)
+    gs = t(rng.normal(0, 1, (B, W, W, 32)))
+    gl = t(rng.normal(0, 1, (B, W, W, 2)))
+
+    def run(dec):
+        xg = x.clone().requires_grad_(True)
+        out = dec(xg)
+        loss = (out["seg"] * gs).sum()
+        if with_silh:
+            loss = loss + (out["silhouette"] * gl).sum()
+        loss.backward()
+        return xg.grad.clone()
+
+    det = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, deterministic=True)
+    first = run(det)
+    for _ in range(4):
+        assert torch.equal(run(det), first)
+    ref = run(SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh))
+    grad_close(first.cpu().numpy(), ref.cpu().numpy(), 1e-5, "deterministic vs default dx")
+    assert torch.isfinite(first).all()
+
+
+def test_deterministic_rasteriser_ops_and_scaling(layer_inputs=None):
+    """The stand-alone ops with deterministic=True: bit-identical dproj across runs, equal to the default's to
+    rounding, and invariant to the cotangent's magnitude (the fixed-point scale follows max|dseg|): dproj(c g) =
+    c dproj(g) to fp32 rounding for c = 2^-60 ... 2^40."""
+    from ilps_amd.keras_smpl.batch_smpl import SMPLLayer
+    from ilps_amd.keras_smpl.compute_mask import compute_mask
+    from ilps_amd.keras_smpl.projection import orthographic_project
+    from ilps_amd.keras_smpl.projects_to_seg import projects_to_seg
+    from ilps_amd.keras_smpl.projects_to_silhouette import projects_to_silhouette
+    from ilps_amd.smpl_model import synthetic_smpl_model
+    W, B = 48, 3
+    layer = SMPLLayer(synthetic_smpl_model(1234))
+    x = t(make_x(B, W, seed=33))
+    proj = orthographic_project([layer(x), x], None).detach()
+    mask = compute_mask(proj)
+    rng = np.random.default_rng(2)
+    g = t(rng.normal(0, 1, (B, W, W, 32)))
+    gl = t(rng.normal(0, 1, (B, W, W, 2)))
+
+    def dseg(c, det):
+        p = proj.clone().requires_grad_(True)
+        (projects_to_seg([p, mask], W, deterministic=det) * (g * c)).sum().backward()
+        return p.grad
+
+    def dsil(c, det):
+        p = proj.clone().requires_grad_(True)
+        (projects_to_silhouette(p, W, deterministic=det) * (gl * c)).sum().backward()
+        return p.grad
+
+    for fn, name in ((dseg, "seg"), (dsil, "silh")):
+        a = fn(1.0, True)
+        assert torch.equal(a, fn(1.0, True)) and torch.equal(a, fn(1.0, True))
+        grad_close(a.cpu().numpy(), fn(1.0, False).cpu().numpy(), 1e-5, name + " det vs default")
+        for c in (2.0 ** -60, 2.0 ** 40):
+            b = fn(c, True)
+            grad_close((b / c).cpu().numpy(), a.cpu().numpy(), 1e-6, "%s cotangent x %g" % (name, c))
+        assert float(fn(0.0, True).abs().max()) == 0.0
