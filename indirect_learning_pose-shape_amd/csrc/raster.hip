@@ -1446,9 +1446,6 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
     int t = 0;
     if (lane == 0) t = atomicAdd(&s_next_tile, 1);
     t = __builtin_amdgcn_readfirstlane(t);
-#ifdef SPX_SKIPPIX
-    break;
-#endif
     if (t >= nloc) break;
     const int tile = t * (int)gridDim.y + (int)blockIdx.y;
     const int ty = tile / tpr, tx = tile - ty * tpr;
@@ -1502,9 +1499,6 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
         rows = 0ull;
       }
     }
-#ifdef SPX_SKIP3
-    rows = 0ull;
-#endif
     // (3) A cell (x, y) is a candidate iff max(|x - cx| - 0.5, 0)^2 + max(|y - cy| - 0.5, 0)^2 <= lim, i.e. row by
     // row |y - cy| <= 0.5 + sqrt(lim) and |x - cx| <= 0.5 + sqrt(lim - dym^2) (1e-4 covers the approximate roots)
     if (lim >= 0.0f) {

@@ -918,3 +918,21 @@ def test_full_size_step_is_repeatable_and_linear(smpl_model):
     _, d12 = run(0.5 * g1 - 2.0 * g2)
     grad_close(d12.cpu().numpy(), (0.5 * d1 - 2.0 * d2).cpu().numpy(), 1e-4, "dx linearity")
     assert torch.isfinite(d12).all()
+
+
+def test_sticky_visibility_module(layer):
+    """The opt-in StickyVisibility (compute_mask.py:68-70: one never-reset mask variable): sample n of call k sees
+    the union of the winners of every earlier sample and call; reset() restores the stateless result."""
+    from ilps_amd.keras_smpl.compute_mask import StickyVisibility, compute_mask
+    _, _, proj = _decoder_inputs(layer, 4, 48, 131)
+    proj = proj.detach()
+    fresh = compute_mask(proj).cpu().numpy()
+    sv = StickyVisibility()
+    got = sv(proj).cpu().numpy()
+    want = np.minimum.accumulate(fresh, axis=0)
+    assert np.array_equal(got, want) and np.array_equal(got[0], fresh[0])
+    assert (got[3] == 1).sum() > (fresh[3] == 1).sum()          # the visible set grew
+    again = sv(proj[:2]).cpu().numpy()                           # state carried into the next call
+    assert np.array_equal(again, np.minimum(np.minimum.accumulate(fresh[:2], axis=0), want[3]))
+    sv.reset()
+    assert np.array_equal(sv(proj[1:2]).cpu().numpy(), fresh[1:2])
