@@ -192,11 +192,14 @@ def raster_roofline(x, consts, pt, W, stages):
             q = json.load(open(sq))
             cyc = q["kernel_us"] * 1e-6 * q["clock_hz"] * q["simds"]      # SIMD-cycles the kernel had
             out["valu_active_frac"] = round(4.0 * q["SQ_ACTIVE_INST_VALU"] / cyc, 3)
-            out["valu_issue_frac"] = round(q["issue_cycles_per_valu"] * q["SQ_INSTS_VALU"] / cyc, 3)
-            out["valu_source"] = ("profiles/raster_sq.json: SQ_INSTS_VALU x %.1f cycles per wave64 instruction (%s) and "
-                                  "4 x SQ_ACTIVE_INST_VALU (quad-cycles) over %d SIMDs x kernel time x %.2f GHz"
-                                  % (q["issue_cycles_per_valu"], q.get("issue_cycles_source", "probe"), q["simds"],
-                                     q["clock_hz"] / 1e9))
+            out["valu_issue_frac"] = [round(q["issue_cycles_plain"] * q["SQ_INSTS_VALU"] / cyc, 3),
+                                      round(q["issue_cycles_packed"] * q["SQ_INSTS_VALU"] / cyc, 3)]
+            out["valu_source"] = ("profiles/raster_sq.json: valu_active_frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) and "
+                                  "valu_issue_frac = SQ_INSTS_VALU x [%.2f, %.2f] cycles per wave64 instruction (measured issue "
+                                  "cost of a plain and of a packed / three-operand fp32 instruction at 4 waves per SIMD, %s; "
+                                  "the kernel mixes both), each over %d SIMDs x %.2f us x %.1f GHz nominal"
+                                  % (q["issue_cycles_plain"], q["issue_cycles_packed"], "profiles/r02_valu_issue_probe.txt",
+                                     q["simds"], q["kernel_us"], q["clock_hz"] / 1e9))
         except Exception:
             pass
     return out

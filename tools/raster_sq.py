@@ -1,8 +1,8 @@
 """Builds profiles/raster_sq.json: the SQ counters of raster_fwd_kernel (rocprofv3 --pmc passes of `bench.py --mode
 eager`, tools/pmc.sh) + its kernel-trace average duration, from which bench.py derives `roofline.valu_issue_frac` and
 `valu_active_frac`.  Usage:
-    python tools/raster_sq.py <kernel_stats.csv of the eager trace> <issue cycles per VALU instr, from
-           tools/probes/valu_issue_probe> gpurun_out/pmc_TAG_1 [gpurun_out/pmc_TAG_2 ...]
+    python tools/raster_sq.py <kernel_stats.csv of the eager trace> <issue cycles per plain VALU instr>,<per packed /
+           three-operand instr> (both from tools/probes/valu_issue_probe at 4 waves per SIMD) gpurun_out/pmc_TAG_1 [...]
 """
 import collections
 import csv
@@ -12,7 +12,8 @@ import os
 import sys
 
 KERNEL = "raster_fwd_kernel"
-stats, issue = sys.argv[1], float(sys.argv[2])
+stats = sys.argv[1]
+issue_plain, issue_packed = (float(v) for v in sys.argv[2].split(","))
 us = None
 for r in csv.DictReader(open(stats)):
     if KERNEL in r["Name"]:
@@ -25,8 +26,9 @@ for d in sys.argv[3:]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"kernel": KERNEL, "kernel_us": us, "kernel_us_source": os.path.basename(stats), "simds": 1024, "clock_hz": 2.4e9,
        "clock_note": "nominal peak clock; the clock held under load is lower, so the fractions are lower bounds",
-       "issue_cycles_per_valu": issue,
-       "issue_cycles_source": "tools/probes/valu_issue_probe (profiles/r02_valu_issue_probe.txt), packed and plain fp32 at 4 waves per SIMD",
+       "issue_cycles_plain": issue_plain, "issue_cycles_packed": issue_packed,
+       "issue_cycles_source": "tools/probes/valu_issue_probe (profiles/r02_valu_issue_probe.txt) at 4 waves per SIMD: v_fma_f32 "
+                              "(plain) and v_pk_fma_f32 / v_pk_add_f32 / v_min3_f32 (the pair loop's instructions)",
        "units": "SQ_INSTS_* = wave-instructions; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* = quad-cycles (x4 = cycles), summed over the chip"}
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
