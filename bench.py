@@ -673,6 +673,19 @@ def main():
                                                           "meshes_per_s": round(B / (t_ds * 1e-3), 1)}
             except Exception as e:
                 line["aux"]["decoder_with_silhouette"] = {"error": str(e)}
+            # the same step with the bit-reproducible backward (SMPLDecoder(deterministic=True): 64-bit fixed-point
+            # accumulation in seg_bwd instead of fp32 LDS atomics) - its price
+            try:
+                def step_det():
+                    xg = x.detach().requires_grad_(True)
+                    _v, _p, _m, sg_, _s, _j = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1, True)
+                    sg_.backward(dseg)
+                step_det()
+                t_dd = graph_time_ms(step_det, 5, torch.cuda.current_stream())
+                line["aux"]["deterministic_step"] = {"ms_per_step": round(t_dd, 4), "meshes_per_s": round(B / (t_dd * 1e-3), 1),
+                                                     "note": "gradients bit-identical run to run (tests/test_gpu_baseline_sizes.py)"}
+            except Exception as e:
+                line["aux"]["deterministic_step"] = {"error": str(e)}
             # loss head: softmax + focal loss on the (B,W,W,32) scores, HBM-bound.
             # algorithmic bytes: fwd = scores 128 + label 4 + loss 4 B/pixel; bwd = 128 + 4 + 4 + 128 B/pixel
             seg_s = torch.rand(B, W, W, 32, device=dev)

@@ -101,6 +101,15 @@ size_t smplr_blend3_bwd_bytes(int N3);
 int smplr_blend3_pack(const float *blend, int N3, void *pk_fwd, void *pk_bwd, void *stream);
 int smplr_blend3_fwd(const void *coef3, const void *pk_fwd, const float *v_template,
                      int B, int N3, float *v_posed, void *stream);
+/* smplr_pose_fwd + smplr_blend3_fwd in ONE launch (what the decoder runs): the first ceil(B/4) workgroups are the
+ * pose kernel (Rs, J, A, J_transformed as smplr_pose_fwd writes them), every GEMM wave computes the coefficient rows
+ * of its own 32 meshes itself instead of reading coef3 - same Rodrigues, same three-way split, so v_posed is what
+ * the two separate calls give, bit for bit - and nothing is handed between workgroups.  The pose chain's latency
+ * (10 us at B = 128) disappears under the GEMM.                                                          */
+int smplr_pose_blend3_fwd(const float *x, int x_stride, int num_cam, int B, const float *J_template,
+                          const float *J_dirs, const int32_t *parents, const void *pk_fwd,
+                          const float *v_template, int N3, float *Rs, float *J, float *A,
+                          float *J_transformed, float *v_posed, void *stream);
 size_t smplr_blend3_bwd_workspace(int B, int N3);
 int smplr_blend3_bwd(const float *dv_posed, const void *pk_bwd, int B, int N3,
                      float *dcoef, void *workspace, void *stream);

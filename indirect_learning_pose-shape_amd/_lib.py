@@ -37,6 +37,7 @@ SIGNATURES = {
     "smplr_blend3_bwd_bytes": (c_size_t, [I]),
     "smplr_blend3_pack": (c_int, [P, I, P, P, P]),
     "smplr_blend3_fwd": (c_int, [P, P, P, I, I, P, P]),
+    "smplr_pose_blend3_fwd": (c_int, [P, I, I, I, P, P, P, P, P, I, P, P, P, P, P, P]),
     "smplr_blend3_bwd_workspace": (c_size_t, [I, I]),
     "smplr_blend3_bwd": (c_int, [P, P, I, I, P, P, P]),
     "smplr_skin_fwd": (c_int, [P, P, P, P, P, I, I, I, I, P, P, P]),

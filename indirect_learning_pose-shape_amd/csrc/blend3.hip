@@ -32,6 +32,7 @@
 //       element j of lane (i, h) = split_s(blend[32u + i][16 kt + 8h + j])
 // (zeros beyond row 219 / column N3 - 1).
 #include "common.h"
+#include "pose_device.h"
 
 namespace smplr {
 
@@ -180,6 +181,159 @@ __global__ __launch_bounds__(256) void blend3_fwd_kernel(const u32x4 *__restrict
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef SMPLR_LOAD_KT
+
+  float base[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) base[t] = vt[min(c + t, N3 - 1)];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int m = m0 + row;
+    if (m < B) {
+      float *o = out + (size_t)m * N3 + c;
+      if (c + 3 <= N3) {
+        f32x3u v;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) v[t] = (hi[t][r] + lo[t][r]) + base[t];
+        *reinterpret_cast<f32x3u *>(o) = v;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (c + t < N3) o[t] = (hi[t][r] + lo[t][r]) + base[t];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pose + blend forward in ONE launch (what the decoder runs; pose_fwd_kernel + blend3_fwd_kernel remain as the
+// stand-alone entry points and give the same bits).  pose_fwd is a chain of dependent steps on one wave per mesh -
+// 10 us at B = 128 for 5 kFLOP per mesh - and the GEMM waited for it only because it read the coefficient
+// fragments that kernel wrote.  Here
+//   * the first ceil(B / 8) workgroups ARE pose_fwd (one wave per mesh: Rs, J, A, J_transformed), and
+//   * a GEMM workgroup is 8 waves, two per SIMD: waves 0..3 multiply (one 32-mesh tile each, as in
+//     blend3_fwd_kernel), waves 4..7 PRODUCE their partners' operand - the coefficient rows [beta | Rs[1:] - I | 0] of
+//     the tile's 32 meshes, Rodrigues of two joints per mesh and step with the same `rodrigues()` as pose_fwd, into
+//     29 KB of LDS - and publish a step counter in LDS; the multiplying wave waits for the steps k-tile kt reads
+//     (coefficients 16 kt .. 16 kt + 15, i.e. joints <= 2 kt + 2 = steps 0..kt), reads its eight values and splits
+//     them into the three bf16 terms with the same `split8()` - the operand is the one pose_fwd would have written,
+//     bit for bit.  The producer's ~2 000 vector instructions issue beside the partner's MFMAs (a wave alone on a
+//     SIMD issues one vector instruction per 5 cycles whatever the matrix pipe does: computed by the multiplying
+//     wave itself they cost 6 us, in front of the loop or interleaved with it alike).
+// Nothing is handed from workgroup to workgroup: the two roles write different outputs, and the chain's latency is
+// hidden under the GEMM on compute units the GEMM leaves idle (216 + 16 workgroups at B = 128 on 256 CUs).
+constexpr int FC_LD = 228;           // floats per mesh row of the staged coefficients (16-B aligned rows, bank-skewed)
+constexpr int F3F_DEPTH = 2;         // k-tiles of the constant in flight (two waves per SIMD: 256 registers each)
+constexpr int PB_MPB = 8;            // meshes per workgroup in the pose role
+
+__global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
+    const float *__restrict__ x, int x_stride, int num_cam, int B, const float *__restrict__ J_template,
+    const float *__restrict__ J_dirs, const int *__restrict__ parents, const u32x4 *__restrict__ pk,
+    const float *__restrict__ vt, int N3, int ntiles, int npose, float *__restrict__ Rs_out,
+    float *__restrict__ J_out, float *__restrict__ A_out, float *__restrict__ newJ_out, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int s_step[4];                                 // GEMM role: coefficient steps published per mesh tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x < npose) {                           // ---- role 1: pose_fwd for 8 meshes
+    PoseLds *lds = reinterpret_cast<PoseLds *>(smem);
+    float *sCoef = smem + (PB_MPB * sizeof(PoseLds) + 15) / 16 * 4;
+    pose_fwd_wave(x, x_stride, num_cam, B, blockIdx.x * PB_MPB + wave, lane, J_template, J_dirs, parents, nullptr, 0,
+                  nullptr, Rs_out, J_out, A_out, newJ_out, lds[wave], sCoef + wave * 224);
+    return;
+  }
+  // ---- role 2: a 96-column tile of the GEMM for 4 x 32 meshes
+  if (tid < 4) s_step[tid] = 0;
+  __syncthreads();
+  const int gb = blockIdx.x - npose;
+  const int ct = gb % ntiles, grp = gb / ntiles;
+  const int mw = wave & 3;                                  // mesh tile of this wave (multiplier w, producer w + 4)
+  const int m0 = (grp * 4 + mw) * 32;
+  if (m0 >= B) return;                                      // this pair's mesh tile is empty (both waves leave)
+  const int i = lane & 31, h = lane >> 5;
+  float *sc = smem + mw * (32 * FC_LD);
+  if (wave >= 4) {
+    // ---- producer: lane (i, h) takes joint 2 s + 1 + h of mesh i in step s (rows beyond B repeat mesh B - 1)
+    float th[12][3];
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+      const int j = min(2 * st + 1 + h, 23);
+      const float *xr = x + (size_t)min(m0 + i, B - 1) * x_stride + num_cam + 3 * j;
+      th[st][0] = xr[0]; th[st][1] = xr[1]; th[st][2] = xr[2];
+    }
+    float be[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int e = lane + 64 * t, mi = e / 10, k = e - 10 * mi;
+      be[t] = x[(size_t)min(m0 + mi, B - 1) * x_stride + num_cam + 72 + k];
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int e = lane + 64 * t, mi = e / 10, k = e - 10 * mi;
+      sc[mi * FC_LD + k] = be[t];
+    }
+    for (int e = lane; e < 32 * 7; e += 64) sc[(e / 7) * FC_LD + 217 + e % 7] = 0.0f;       // 217..223
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+      const int j = 2 * st + 1 + h;
+      float R[9];
+      rodrigues(th[st], R);
+      if (j <= 23) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          sc[i * FC_LD + 10 + 9 * (j - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+      }
+      wave_sync();                                          // this wave's LDS writes have landed ...
+      if (lane == 0) __hip_atomic_store(&s_step[mw], st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... publish
+    }
+    return;
+  }
+  // ---- multiplier
+  const int c = ct * F3_BN + 3 * i;
+  const u32x4 *bp = pk + (size_t)ct * (NKT * 9 * 64) + lane;
+  u32x4 b[F3F_DEPTH + 1][9];
+#define SMPLR_LOAD_B(slot, kt) \
+  { _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) b[slot][j_] = bp[((kt) * 9 + j_) * 64]; }
+#pragma unroll
+  for (int kt = 0; kt < F3F_DEPTH; ++kt) { SMPLR_LOAD_B(kt % (F3F_DEPTH + 1), kt) }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 hi[3], lo[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hi[t][r] = 0.0f; lo[t][r] = 0.0f; }
+  const float *arow = sc + i * FC_LD + 8 * h;
+  // the eight coefficients of k-tile kt for this lane, once the producer has published the steps it reads
+#define SMPLR_WAIT_READ(kt, x0_, x1_)                                                                       \
+  {                                                                                                         \
+    const int need_ = (kt) + 1 < 12 ? (kt) + 1 : 12;                                                        \
+    while (__hip_atomic_load(&s_step[mw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need_)          \
+      __builtin_amdgcn_s_sleep(1);                                                                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                  \
+    x0_ = *reinterpret_cast<const float4 *>(arow + 16 * (kt));                                              \
+    x1_ = *reinterpret_cast<const float4 *>(arow + 16 * (kt) + 4);                                          \
+  }
+  float4 x0, x1;
+  SMPLR_WAIT_READ(0, x0, x1)
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    if (kt + F3F_DEPTH < NKT) { SMPLR_LOAD_B((kt + F3F_DEPTH) % (F3F_DEPTH + 1), kt + F3F_DEPTH) }
+    __builtin_amdgcn_sched_barrier(0);
+    const int s = kt % (F3F_DEPTH + 1);
+    const float xk[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    const Frag3 A = split8(xk);
+    if (kt + 1 < NKT) SMPLR_WAIT_READ(kt + 1, x0, x1)        // the next tile's values arrive under this tile's MFMAs
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, b[s][t * 3 + 0]);
+      const bf16x8 bm = __builtin_bit_cast(bf16x8, b[s][t * 3 + 1]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, b[s][t * 3 + 2]);
+      SMPLR_MFMA_X3(A, bh, bm, bl, hi[t], lo[t])
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SMPLR_WAIT_READ
+#undef SMPLR_LOAD_B
 
   float base[3];
 #pragma unroll
@@ -403,6 +557,32 @@ int smplr_blend3_fwd(const void *coef3, const void *pk_fwd, const float *v_templ
                      reinterpret_cast<const u32x4 *>(coef3), reinterpret_cast<const u32x4 *>(pk_fwd), v_template, B,
                      N3, v_posed);
   SMPLR_LAUNCH_CHECK("smplr_blend3_fwd");
+  return 0;
+}
+
+int smplr_pose_blend3_fwd(const float *x, int x_stride, int num_cam, int B, const float *J_template,
+                          const float *J_dirs, const int32_t *parents, const void *pk_fwd, const float *v_template,
+                          int N3, float *Rs, float *J, float *A, float *J_transformed, float *v_posed, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B >= 0 && N3 > 0 && num_cam >= 0 && num_cam <= 16 && x_stride >= num_cam + 82,
+                "smplr_pose_blend3_fwd: bad sizes B=%d N3=%d num_cam=%d x_stride=%d", B, N3, num_cam, x_stride);
+  if (B == 0) return 0;
+  SMPLR_REQUIRE(x && J_template && J_dirs && parents && pk_fwd && v_template && Rs && J && A && J_transformed && v_posed,
+                "smplr_pose_blend3_fwd: null pointer");
+  const int ntiles = (N3 + F3_BN - 1) / F3_BN, ngroups = (B + 127) / 128, npose = (B + PB_MPB - 1) / PB_MPB;
+  const size_t lds_gemm = (size_t)4 * 32 * FC_LD * sizeof(float);
+  const size_t lds_pose = (PB_MPB * sizeof(PoseLds) + 15) / 16 * 16 + (size_t)PB_MPB * 224 * sizeof(float);
+  const size_t lds = lds_gemm > lds_pose ? lds_gemm : lds_pose;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pose_blend3_fwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pose_blend3_fwd_kernel, dim3(npose + ntiles * ngroups), dim3(512), lds, as_stream(stream), x, x_stride,
+                     num_cam, B, J_template, J_dirs, parents, reinterpret_cast<const u32x4 *>(pk_fwd), v_template, N3,
+                     ntiles, npose, Rs, J, A, J_transformed, v_posed);
+  SMPLR_LAUNCH_CHECK("smplr_pose_blend3_fwd");
   return 0;
 }
 

@@ -192,6 +192,25 @@ def _pose_fwd(x, num_cam, c: SMPLConstants, out=None, want=None):
 
 
 @on_device
+def _pose_blend_fwd(x, num_cam, c: SMPLConstants, out=None, v_posed=None):
+    """smplr_pose_blend3_fwd: pose kernel + blend GEMM in one launch (bf16x3 constants only) -> Rs, J, A, Jt, v_posed;
+    bit-identical to _pose_fwd followed by _blend_fwd."""
+    lib = _lib.load()
+    if c.blend3_fwd is None:
+        raise RuntimeError("the fused pose + blend launch needs the bf16x3 constants (SMPLConstants.pack_blend3)")
+    B = x.shape[0]
+    if out is None:
+        out = (_empty((B, 24, 9), x), _empty((B, 24, 3), x), _empty((B, 24, 12), x), _empty((B, 24, 3), x))
+    Rs, J, A, Jt = out
+    if v_posed is None:
+        v_posed = _empty((B, c.V, 3), x)
+    check(lib.smplr_pose_blend3_fwd(ptr(x), x.shape[1], num_cam, B, ptr(c.J_template), ptr(c.J_dirs), ptr(c.parents),
+                                    ptr(c.blend3_fwd), ptr(c.v_template), 3 * c.V, ptr(Rs), ptr(J), ptr(A), ptr(Jt),
+                                    ptr(v_posed), stream()), "smplr_pose_blend3_fwd")
+    return Rs, J, A, Jt, v_posed
+
+
+@on_device
 def _blend_fwd(coef: PoseCoef, c: SMPLConstants, B, out=None):
     """coef: what _pose_fwd returned for the same B meshes."""
     lib = _lib.load()
@@ -391,8 +410,11 @@ class BatchSMPLFn(torch.autograd.Function):
     def forward(ctx, x, consts: SMPLConstants, num_cam: int):
         x = require_cuda(x, "x")
         ctx.set_materialize_grads(False)
-        coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
-        v_posed = _blend_fwd(coef, consts, x.shape[0])
+        if consts.blend3_fwd is not None:
+            Rs, J, A, Jt, v_posed = _pose_blend_fwd(x, num_cam, consts)        # one launch
+        else:
+            coef, Rs, J, A, Jt = _pose_fwd(x, num_cam, consts)
+            v_posed = _blend_fwd(coef, consts, x.shape[0])
         verts, _ = _skin_fwd(v_posed, A, consts)
         ctx.consts, ctx.num_cam = consts, num_cam
         ctx.save_for_backward(x, Rs, J, A, v_posed)
@@ -786,8 +808,11 @@ class DecoderFn(torch.autograd.Function):
 
         def run(lo, hi):
             xs = x[lo:hi]
-            coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
-            _blend_fwd(coef, consts, hi - lo, out=v_posed[lo:hi])
+            if consts.blend3_fwd is not None:
+                _pose_blend_fwd(xs, num_cam, consts, out=(Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]), v_posed=v_posed[lo:hi])
+            else:
+                coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
+                _blend_fwd(coef, consts, hi - lo, out=v_posed[lo:hi])
             _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
                       out=(verts[lo:hi], proj[lo:hi]))
             _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,

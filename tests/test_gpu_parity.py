@@ -936,3 +936,18 @@ def test_sticky_visibility_module(layer):
     assert np.array_equal(again, np.minimum(np.minimum.accumulate(fresh[:2], axis=0), want[3]))
     sv.reset()
     assert np.array_equal(sv(proj[1:2]).cpu().numpy(), fresh[1:2])
+
+
+@pytest.mark.parametrize("B", [1, 5, 33, 128, 200])
+def test_fused_pose_blend_equals_separate_calls(smpl_model, B):
+    """smplr_pose_blend3_fwd (pose kernel + blend GEMM in one launch, what the decoder runs) == smplr_pose_fwd followed
+    by smplr_blend3_fwd, bit for bit: Rs, J, A, J_transformed and v_posed (ragged last mesh tile, several groups)."""
+    from ilps_amd import ops
+    c = ops.SMPLConstants.from_model(smpl_model, dev()).pack_blend3()
+    x = t(make_x(B, 48, seed=700 + B))
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
+    vp = ops._blend_fwd(coef, c, B)
+    Rs2, J2, A2, Jt2, vp2 = ops._pose_blend_fwd(x, 4, c)
+    torch.cuda.synchronize()
+    for a, b, name in ((Rs, Rs2, "Rs"), (J, J2, "J"), (A, A2, "A"), (Jt, Jt2, "J_transformed"), (vp, vp2, "v_posed")):
+        assert torch.equal(a, b), name
