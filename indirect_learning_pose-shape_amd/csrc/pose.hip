@@ -95,9 +95,12 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
   // this lane's joint angles, needed only by the Rodrigues backward at the very end: requested with everything
   // else (a load there sat alone on the critical path)
   float th[3] = {0.f, 0.f, 0.f};
+  int tdesc = 0, tchild = 0;                       // the SMPL tree's masks for joint `tid`, requested with the rest
   if (tid < 24) {
     const float *xr0 = x + nn * x_stride + num_cam + 3 * tid;
     th[0] = xr0[0]; th[1] = xr0[1]; th[2] = xr0[2];
+    tdesc = SMPL_TREE_DESC[tid];
+    tchild = SMPL_TREE_CHILD[tid];
   }
   for (int e = tid; e < 720; e += PBW) sJd[e] = J_dirs[e];
   for (int e = tid; e < 216; e += PBW) L.Rs[e / 9][e % 9] = Rs_in[nn * 216 + e];
@@ -134,11 +137,9 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
     }
   }
   __syncthreads();
-  if (tid >= 64) return;                                 // the rest is one wavefront's work
-  const int par = parents[lane < 24 ? lane : 0];         // parent(i) by v_readlane in the chain loop
-  wave_sync();
-  if (live && lane < 24) {
-    const int i = lane;
+  const int par = parents[lane < 24 ? lane : 0];
+  if (tid < 24) {
+    const int i = tid;
     const float *dAi = &L.dA[i][0];
     float dAt[3] = {dAi[3], dAi[7], dAi[11]};
 #pragma unroll
@@ -150,34 +151,111 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       L.dJ[i][c] = -(L.G[i][0 * 4 + c] * dAt[0] + L.G[i][1 * 4 + c] * dAt[1] + L.G[i][2 * 4 + c] * dAt[2]);
-  }
-  wave_sync();
+    // t_i = A_i.t + G_i.R J_i, the world position of joint i (dA_i has just been consumed, by this thread)
 #pragma unroll
-  for (int i = 23; i >= 1; --i) {
-    const int p = __builtin_amdgcn_readlane(par, i);
-    float upd = 0.f;
-    if (live && lane < 9) {
-      const int r = lane / 3, c = lane % 3;
-      // dR_i = Gp.R^T dGR_i
-      L.dR[i][lane] = L.G[p][0 * 4 + r] * L.dGR[i][0 * 3 + c] + L.G[p][1 * 4 + r] * L.dGR[i][1 * 3 + c] +
-                      L.G[p][2 * 4 + r] * L.dGR[i][2 * 3 + c];
-      // dGR_p += dGR_i R_i^T + dGt_i (x) (J_i - J_p)
-      upd = L.dGR[i][r * 3 + 0] * L.Rs[i][c * 3 + 0] + L.dGR[i][r * 3 + 1] * L.Rs[i][c * 3 + 1] +
-            L.dGR[i][r * 3 + 2] * L.Rs[i][c * 3 + 2] + L.dGt[i][r] * (L.J[i][c] - L.J[p][c]);
-      L.dGR[p][lane] += upd;
-    } else if (live && lane >= 16 && lane < 19) {
-      const int c = lane - 16;
-      L.dGt[p][c] += L.dGt[i][c];
-      const float tmp = L.G[p][0 * 4 + c] * L.dGt[i][0] + L.G[p][1 * 4 + c] * L.dGt[i][1] +
-                        L.G[p][2 * 4 + c] * L.dGt[i][2];
-      L.dJ[i][c] += tmp;
-      L.dJ[p][c] -= tmp;
-    }
-    wave_sync();
+    for (int r = 0; r < 3; ++r)
+      L.dA[i][9 + r] = L.G[i][r * 4 + 3] + (L.G[i][r * 4 + 0] * L.J[i][0] + L.G[i][r * 4 + 1] * L.J[i][1] +
+                                            L.G[i][r * 4 + 2] * L.J[i][2]);
   }
-  if (live && lane < 9) L.dR[0][lane] = L.dGR[0][lane];
-  if (live && lane >= 16 && lane < 19) L.dJ[0][lane - 16] += L.dGt[0][lane - 16];
-  wave_sync();
+  if (tid < 64) {
+    // masks of the tree: the standard SMPL tree's from the tables, any other tree's by walking up (lanes = joints)
+    const bool smpl_tree = is_smpl_tree(par, lane);                     // wave-uniform
+    int desc = tdesc, child = tchild;
+    if (!smpl_tree) {
+      int anc = 1 << (lane & 31), p = lane < 24 ? par : -1;
+      for (int it = 0; it < 23; ++it) {                               // uniform trip count: shuffles need every lane
+        anc |= (p >= 0) ? 1 << p : 0;
+        const int pp = __shfl(par, p >= 0 ? p : 0, 64);
+        p = (p >= 0) ? pp : -1;
+      }
+      desc = 0;
+      child = 0;
+      for (int d = 0; d < 24; ++d) {
+        desc |= ((__shfl(anc, d, 64) >> (lane & 31)) & 1) << d;
+        child |= (__shfl(par, d, 64) == lane ? 1 : 0) << d;
+      }
+    }
+    if (lane < 24) {
+      L.desc[lane] = desc;
+      L.child[lane] = child;
+      L.par[lane] = par;
+    }
+  }
+  __syncthreads();
+  // The chain, in closed form.  The recursion (children before parents)
+  //     dGR_p += dGR_i R_i^T + dGt_i (x) (J_i - J_p),   dGt_p += dGt_i,   dR_i = G_p.R^T dGR_i
+  // is 23 dependent LDS round trips on ONE wave (6.8 us of this kernel's 13.4).  Written in the world frame -
+  // H_i = dGR_i G_i.R^T, with G_c.R R_c^T = G_p.R and J_c - J_p = G_p.R^T (t_c - t_p), t = world joint positions - it
+  // telescopes into sums over subtrees:
+  //     dGt_i = sum_{d in sub(i)} dGt_d^0,        H_i = sum_{d in sub(i)} Z_d - Y_i,
+  //     Z_d = dGR_d^0 G_d.R^T + Y_d,   Y_d = dGt_d (x) (t_d - t_parent(d))  (Y_root = 0),
+  //     dR_i = G_p.R^T H_i G_i.R   (root: H_0 G_0.R),
+  //     dJ_i = dJ_i^0 + G_p.R^T dGt_i - sum_{c child of i} G_i.R^T dGt_c   (root: + dGt_0),
+  // i.e. five phases whose items (joint x matrix element, one per thread of the workgroup) are independent, the
+  // subtree sums taken in index order from each joint's descendant mask: the same gradient, a fixed summation
+  // order, all eight waves instead of one.
+  // scratch: L.dA[i][0..8] = Z_i, then T_i = H_i G_i.R;  L.dA[i][9..11] = t_i;  L.dGR = H
+  if (tid < 72) {                                          // P1: dGt over subtrees
+    const int i = tid / 3, r = tid - 3 * i, m = L.desc[i];
+    // (every joint is read, the mask picks the terms: unconditional reads are all in flight together, a test around
+    // each read serialises 24 LDS round trips)
+    float v[24];
+#pragma unroll
+    for (int d = 0; d < 24; ++d) v[d] = L.dGt[d][r];
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 24; ++d) acc += ((m >> d) & 1) ? v[d] : 0.0f;
+    L.dGtF[i][r] = acc;
+  }
+  __syncthreads();
+  const int ci = tid / 9, ce = tid - 9 * ci, cr = ce / 3, cc = ce - 3 * cr;   // this thread's (joint, row, column) for tid < 216
+  if (tid < 216) {                                         // P2: Z_d
+    const int p = L.par[ci];
+    float z = L.dGR[ci][cr * 3 + 0] * L.G[ci][cc * 4 + 0] + L.dGR[ci][cr * 3 + 1] * L.G[ci][cc * 4 + 1] +
+              L.dGR[ci][cr * 3 + 2] * L.G[ci][cc * 4 + 2];
+    if (p >= 0) z += L.dGtF[ci][cr] * (L.dA[ci][9 + cc] - L.dA[p][9 + cc]);
+    L.dA[ci][ce] = z;
+  }
+  __syncthreads();
+  if (tid < 216) {                                         // P3: sums of Z over subtrees, minus Y_i -> H_i
+    const int m = L.desc[ci], p = L.par[ci];
+    float v[24];
+#pragma unroll
+    for (int d = 0; d < 24; ++d) v[d] = L.dA[d][ce];
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 24; ++d) acc += ((m >> d) & 1) ? v[d] : 0.0f;
+    if (p >= 0) acc -= L.dGtF[ci][cr] * (L.dA[ci][9 + cc] - L.dA[p][9 + cc]);
+    L.dGR[ci][ce] = acc;
+  }
+  __syncthreads();
+  if (tid < 216) {                                         // P4: T_i = H_i G_i.R
+    L.dA[ci][ce] = L.dGR[ci][cr * 3 + 0] * L.G[ci][0 * 4 + cc] + L.dGR[ci][cr * 3 + 1] * L.G[ci][1 * 4 + cc] +
+                   L.dGR[ci][cr * 3 + 2] * L.G[ci][2 * 4 + cc];
+  } else if (tid >= 256 && tid < 328) {                    //     and G_p.R^T dGt_i
+    const int it = tid - 256, i = it / 3, c = it - 3 * i, p = L.par[i];
+    L.tmpv[i][c] = (p >= 0) ? L.G[p][0 * 4 + c] * L.dGtF[i][0] + L.G[p][1 * 4 + c] * L.dGtF[i][1] +
+                                  L.G[p][2 * 4 + c] * L.dGtF[i][2]
+                            : L.dGtF[i][c];
+  }
+  __syncthreads();
+  if (tid < 216) {                                         // P5: dR_i = G_p.R^T T_i
+    const int p = L.par[ci];
+    L.dR[ci][ce] = (p >= 0) ? L.G[p][0 * 4 + cr] * L.dA[ci][0 * 3 + cc] + L.G[p][1 * 4 + cr] * L.dA[ci][1 * 3 + cc] +
+                                  L.G[p][2 * 4 + cr] * L.dA[ci][2 * 3 + cc]
+                            : L.dA[ci][ce];
+  } else if (tid >= 256 && tid < 328) {                    //     and dJ_i
+    const int it = tid - 256, i = it / 3, c = it - 3 * i, m = L.child[i];
+    float v[24];
+#pragma unroll
+    for (int d = 0; d < 24; ++d) v[d] = L.tmpv[d][c];
+    float acc = L.dJ[i][c] + L.tmpv[i][c];
+#pragma unroll
+    for (int d = 0; d < 24; ++d) acc -= ((m >> d) & 1) ? v[d] : 0.0f;
+    L.dJ[i][c] = acc;
+  }
+  __syncthreads();
+  if (tid >= 64) return;                                 // the rest is one wavefront's work
   // d beta = dcoef[0..9] + J_dirs^T dJ: 10 x 72 products, over 60 lanes (6 chunks of 12 per beta; the 10 serial
   // 72-term sums took 0.6 us between two divergent branches), chunk sums parked in L.dA (free by now)
   float *scratch = &L.dA[0][0];
