@@ -93,7 +93,8 @@ def graph_time_ms(fn, reps, stream):
 
 
 def stage_breakdown(x, consts, pt, W, reps=20):
-    """Per-C-ABI-call mean times (us) on the current stream; same kernels, same call sequence as the timed step."""
+    """Per-C-ABI-call mean times (us) on the current stream: the calls of the timed step (pose_blend_fwd(fused), skin_fwd,
+    vis_seg_fwd, seg_bwd, smpl_bwd) plus the two stand-alone calls the fused forward launch replaces (pose_fwd, blend_fwd)."""
     st = torch.cuda.current_stream()
     B = x.shape[0]
     VP = consts.V
@@ -102,6 +103,9 @@ def stage_breakdown(x, consts, pt, W, reps=20):
     res["pose_fwd"] = graph_time_ms(lambda: ops._pose_fwd(x, 4, consts), reps, st)
     v_posed = ops._blend_fwd(coef, consts, B)
     res["blend_fwd"] = graph_time_ms(lambda: ops._blend_fwd(coef, consts, B), reps, st)
+    if consts.blend3_fwd is not None:       # what the step runs instead of the two above: one launch
+        bufs = (Rs, J, A, Jt)
+        res["pose_blend_fwd(fused)"] = graph_time_ms(lambda: ops._pose_blend_fwd(x, 4, consts, out=bufs, v_posed=v_posed), reps, st)
     verts, proj = ops._skin_fwd(v_posed, A, consts, cam=x)
     res["skin_fwd"] = graph_time_ms(lambda: ops._skin_fwd(v_posed, A, consts, cam=x), reps, st)
     vslot = torch.empty(B, VP, dtype=torch.int16, device=x.device)
