@@ -11,8 +11,10 @@ parameters that are already resident in HBM.  The path shards by mesh with no da
 bracketed by barrier + synchronize and the MAX over ranks is taken.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      - the dominant kernel (segmentation raster forward), timed live with HIP events on
-                  the launch stream; achieved = algorithmic FLOPs per launch / mean launch time
+  roofline      - the dominant kernel (raster_fwd_kernel alone, smplr_seg_raster), timed live with HIP events on
+                  the launch stream; achieved = FLOPs of the pairs it evaluates (counted on the device) / mean launch
+                  time, frac = achieved / fp32 vector peak (< 1); the brute-force count of SURVEY 8(d) is carried as
+                  algorithmic_speedup; valu_* and traffic come from the committed PMC passes (profiles/)
   cpu_baseline  - the oracle's fp32 reference-shaped torch-CPU restatement timed on this box's host
                   cores on a bounded sample (rank 0, N=1 only); a reported baseline, not the target
 """
