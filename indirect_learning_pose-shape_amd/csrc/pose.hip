@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
   // i.e. five phases whose items (joint x matrix element, one per thread of the workgroup) are independent, the
   // subtree sums taken in index order from each joint's descendant mask: the same gradient, a fixed summation
   // order, all eight waves instead of one.
-  // scratch: L.dA[i][0..8] = Z_i, then T_i = H_i G_i.R;  L.dA[i][9..11] = t_i;  L.dGR = H
+  // scratch: L.dA[i][0..8] = X_i, then T_i = H_i G_i.R;  L.dA[i][9..11] = t_i;  L.tmpv = bone vectors, then G_p.R^T dGt;  L.dGR = H
   if (tid < 72) {                                          // P1: dGt over subtrees
     const int i = tid / 3, r = tid - 3 * i, m = L.desc[i];
     // (every joint is read, the mask picks the terms: unconditional reads are all in flight together, a test around
@@ -209,23 +209,26 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
   }
   __syncthreads();
   const int ci = tid / 9, ce = tid - 9 * ci, cr = ce / 3, cc = ce - 3 * cr;   // this thread's (joint, row, column) for tid < 216
-  if (tid < 216) {                                         // P2: Z_d
-    const int p = L.par[ci];
-    float z = L.dGR[ci][cr * 3 + 0] * L.G[ci][cc * 4 + 0] + L.dGR[ci][cr * 3 + 1] * L.G[ci][cc * 4 + 1] +
-              L.dGR[ci][cr * 3 + 2] * L.G[ci][cc * 4 + 2];
-    if (p >= 0) z += L.dGtF[ci][cr] * (L.dA[ci][9 + cc] - L.dA[p][9 + cc]);
-    L.dA[ci][ce] = z;
+  if (tid < 216) {                                         // P2: X_d = dGR_d^0 G_d.R^T
+    L.dA[ci][ce] = L.dGR[ci][cr * 3 + 0] * L.G[ci][cc * 4 + 0] + L.dGR[ci][cr * 3 + 1] * L.G[ci][cc * 4 + 1] +
+                   L.dGR[ci][cr * 3 + 2] * L.G[ci][cc * 4 + 2];
+  } else if (tid >= 256 && tid < 328) {                    //     and the bone vectors t_d - t_parent(d) (root: 0)
+    const int it = tid - 256, d = it / 3, c = it - 3 * d, p = L.par[d];
+    L.tmpv[d][c] = (p >= 0) ? L.dA[d][9 + c] - L.dA[p][9 + c] : 0.0f;
   }
   __syncthreads();
-  if (tid < 216) {                                         // P3: sums of Z over subtrees, minus Y_i -> H_i
-    const int m = L.desc[ci], p = L.par[ci];
-    float v[24];
+  if (tid < 216) {                                         // P3: H_i = sum_{sub(i)} X_d + sum_{sub(i), d != i} Y_d
+    // (Y_i itself is left out of the sum rather than added and subtracted again: it is of the size of the result)
+    const int m = L.desc[ci], my = m & ~(1 << ci);
+    float vx[24], vg[24], vt[24];
 #pragma unroll
-    for (int d = 0; d < 24; ++d) v[d] = L.dA[d][ce];
+    for (int d = 0; d < 24; ++d) { vx[d] = L.dA[d][ce]; vg[d] = L.dGtF[d][cr]; vt[d] = L.tmpv[d][cc]; }
     float acc = 0.0f;
 #pragma unroll
-    for (int d = 0; d < 24; ++d) acc += ((m >> d) & 1) ? v[d] : 0.0f;
-    if (p >= 0) acc -= L.dGtF[ci][cr] * (L.dA[ci][9 + cc] - L.dA[p][9 + cc]);
+    for (int d = 0; d < 24; ++d) {
+      acc += ((m >> d) & 1) ? vx[d] : 0.0f;
+      acc += ((my >> d) & 1) ? vg[d] * vt[d] : 0.0f;
+    }
     L.dGR[ci][ce] = acc;
   }
   __syncthreads();
