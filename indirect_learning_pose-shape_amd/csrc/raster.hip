@@ -1569,15 +1569,20 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
                                                         const int *__restrict__ arg,
                                                         const float *__restrict__ proj, int VP, int W,
                                                         float *__restrict__ dproj) {
+  // gridDim.y workgroups share a mesh: each owns a contiguous range of VERTICES (its accumulators, its rows of
+  // dproj) and walks all the pixels, taking those whose arg-max vertex is its own - with fewer meshes than compute
+  // units what there is to spread is the zeroing and the 82 KB of dproj per mesh, the pixel walk is short
   extern __shared__ __attribute__((aligned(16))) float acc[];
   unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
   __shared__ unsigned s_gmax;
   const int n = blockIdx.x, tid = threadIdx.x;
+  const int per = (VP + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int v0 = (int)blockIdx.y * per, v1 = min(VP, v0 + per), nv = max(v1 - v0, 0);
   if (DET) {
-    for (int i = tid; i < VP * 2; i += 1024) acc64[i] = 0ull;
+    for (int i = tid; i < nv * 2; i += 1024) acc64[i] = 0ull;
     if (tid == 0) s_gmax = 0u;
   } else {
-    for (int i = tid; i < VP * 2; i += 1024) acc[i] = 0.0f;
+    for (int i = tid; i < nv * 2; i += 1024) acc[i] = 0.0f;
   }
   __syncthreads();
   const int npix = W * W;
@@ -1598,10 +1603,10 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
   const float *pj = proj + (size_t)n * VP * 3;
   for (int o = tid; o < npix; o += 1024) {
     const size_t po = (size_t)n * npix + o;
+    const int v = arg[po];
+    if (v < v0 || v >= v1) continue;                       // (-1: no vertex) another workgroup's vertex
     const float g = dsilh[po * 2 + 1] - dsilh[po * 2];
     const float sc = silh[po * 2 + 1];
-    const int v = arg[po];
-    if (v < 0) continue;
     const int ro = o / W, cc = o - ro * W;
     const float fr = (float)(W - 1 - ro), fc = (float)cc;
     const float du = pj[v * 3] - fc, dv = pj[v * 3 + 1] - fr;
@@ -1609,18 +1614,19 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
     const float k = -g * sc / 1.2f;
     if (d > 0.0f && k != 0.0f) {
       const float kk = k / d;
+      const int a = (v - v0) * 2;
       if (DET) {
-        atomicAdd(&acc64[v * 2], (unsigned long long)__float2ll_rn(kk * du * scale));
-        atomicAdd(&acc64[v * 2 + 1], (unsigned long long)__float2ll_rn(kk * dv * scale));
+        atomicAdd(&acc64[a], (unsigned long long)__float2ll_rn(kk * du * scale));
+        atomicAdd(&acc64[a + 1], (unsigned long long)__float2ll_rn(kk * dv * scale));
       } else {
-        atomicAdd(&acc[v * 2], kk * du);
-        atomicAdd(&acc[v * 2 + 1], kk * dv);
+        atomicAdd(&acc[a], kk * du);
+        atomicAdd(&acc[a + 1], kk * dv);
       }
     }
   }
   __syncthreads();
-  float *o = dproj + (size_t)n * VP * 3;
-  for (int i = tid; i < VP * 3; i += 1024) {
+  float *o = dproj + ((size_t)n * VP + v0) * 3;
+  for (int i = tid; i < nv * 3; i += 1024) {
     const int v = i / 3, c = i - v * 3;
     if (DET) o[i] = (c < 2) ? (float)(long long)acc64[v * 2 + c] * inv_scale : 0.0f;
     else o[i] = (c < 2) ? acc[v * 2 + c] : 0.0f;
@@ -1866,18 +1872,20 @@ int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg, co
   SMPLR_REQUIRE(B >= 0 && VP > 0 && W > 0 && W <= 1024, "smplr_silh_bwd: bad sizes B=%d VP=%d W=%d", B, VP, W);
   if (B == 0) return 0;
   SMPLR_REQUIRE(dsilh && silh && arg && proj && dproj, "smplr_silh_bwd: null pointer");
-  const size_t lds = (size_t)VP * 2 * (deterministic ? sizeof(unsigned long long) : sizeof(float));
+  const int nsplit = B >= 512 ? 1 : (B >= 128 ? 2 : 4);      // workgroups per mesh (vertex ranges)
+  const int per = (VP + nsplit - 1) / nsplit;
+  const size_t lds = (size_t)per * 2 * (deterministic ? sizeof(unsigned long long) : sizeof(float));
   SMPLR_REQUIRE(lds <= 150 * 1024, "smplr_silh_bwd: VP=%d needs %zu B of LDS", VP, lds);
   if (deterministic) {
     int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel<true>), lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(silh_bwd_kernel<true>, dim3(B), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj, VP,
-                       W, dproj);
+    hipLaunchKernelGGL(silh_bwd_kernel<true>, dim3(B, nsplit), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj,
+                       VP, W, dproj);
   } else {
     int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel<false>), lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(silh_bwd_kernel<false>, dim3(B), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj, VP,
-                       W, dproj);
+    hipLaunchKernelGGL(silh_bwd_kernel<false>, dim3(B, nsplit), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj,
+                       VP, W, dproj);
   }
   SMPLR_LAUNCH_CHECK("smplr_silh_bwd");
   return 0;

@@ -25,12 +25,14 @@ def t(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(dev())
 
 
-def grad_close(a, b, rtol=2e-3, name="", elem_rtol=None, elem_atol=2e-4):
+def grad_close(a, b, rtol=2e-3, name="", elem_rtol=None, elem_atol=2e-4, per_column=True):
     """Two bars.  (1) max-norm: max|a-b| <= rtol * max|b|.  (2) element-wise, so that a small entry cannot hide
     behind the largest one (a gradient column like d(beta) or d(cam) is orders of magnitude below d(theta_root)):
     |a-b| <= elem_rtol*|b| + elem_atol*scale, where scale is the RMS of the reference over the batch axis per
     trailing index (a parameter's own typical size; the absolute error of an fp32 sum is proportional to the size
-    of its terms, not to the - possibly cancelled - result).  elem_rtol defaults to rtol."""
+    of its terms, not to the - possibly cancelled - result).  elem_rtol defaults to rtol.  per_column=False takes the
+    RMS of the whole tensor instead (per-vertex tensors such as dproj, where most entries are exact zeros and a vertex'
+    RMS over a batch of 3 is no scale at all)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     assert a.shape == b.shape, "%s: shapes %s vs %s" % (name, a.shape, b.shape)
     if b.size == 0:
@@ -39,7 +41,7 @@ def grad_close(a, b, rtol=2e-3, name="", elem_rtol=None, elem_atol=2e-4):
     err = np.abs(a - b).max() / scale
     assert err <= rtol, "%s: max|diff|/max|ref| = %.3e > %.1e" % (name, err, rtol)
     er = rtol if elem_rtol is None else elem_rtol
-    col = np.sqrt(np.mean(b * b, axis=0, keepdims=True)) if b.ndim >= 2 else np.sqrt(np.mean(b * b))
+    col = np.sqrt(np.mean(b * b, axis=0, keepdims=True)) if (b.ndim >= 2 and per_column) else np.sqrt(np.mean(b * b))
     col = np.maximum(col, 1e-3 * np.sqrt(np.mean(b * b)) + 1e-30)
     bad = np.abs(a - b) > er * np.abs(b) + elem_atol * col
     assert not bad.any(), "%s: %d of %d entries outside |d| <= %.1e|ref| + %.1e*rms; worst %.3e vs ref %.3e" % (
