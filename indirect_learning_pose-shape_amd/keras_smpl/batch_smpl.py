@@ -101,9 +101,12 @@ class SMPLLayer(nn.Module):
 
     @staticmethod
     def batch_global_rigid_transformation(Rs, Js, parent, rotate_base=False):
-        if rotate_base:
-            raise NotImplementedError("rotate_base=True is never used by the reference's callers")
+        """batch_smpl.py:168-228 on device tensors (plain torch: the hot path runs smplr_pose_fwd).  rotate_base=True
+        (:185-190, never used by the reference's callers) turns the root rotation by diag(1, -1, -1)."""
         N = Rs.shape[0]
+        if rotate_base:
+            rot_x = Rs.new_tensor([[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]])
+            Rs = torch.cat([(Rs[:, 0] @ rot_x).unsqueeze(1), Rs[:, 1:]], dim=1)
         res = [None] * 24
         bottom = Rs.new_tensor([0, 0, 0, 1.0]).expand(N, 1, 4)
         mk = lambda R, t: torch.cat([torch.cat([R, t.unsqueeze(-1)], 2), bottom], 1)

@@ -55,14 +55,18 @@ def batch_rodrigues(theta):
     return cos * eyes + (1 - cos) * outer + sin * batch_skew(r[:, :, 0])
 
 
-def batch_global_rigid_transformation(Rs, Js, parent):
-    """`keras_smpl/batch_smpl.py:168-228` (rotate_base=False; the True branch is never used).
+def batch_global_rigid_transformation(Rs, Js, parent, rotate_base=False):
+    """`keras_smpl/batch_smpl.py:168-228`; rotate_base (:185-190, never used by the reference's callers) multiplies the
+    root rotation by diag(1, -1, -1) from the right.
 
     Returns (new_J (N,24,3), A (N,24,4,4)).
     """
     Rs = np.asarray(Rs, F)
     Js = np.asarray(Js, F)
     N = Rs.shape[0]
+    if rotate_base:                                                      # :185-190
+        Rs = Rs.copy()
+        Rs[:, 0] = Rs[:, 0] @ np.diag([1.0, -1.0, -1.0])
     Js = Js[..., None]                                                   # (N,24,3,1)  :194
 
     def make_A(R, t):                                                    # :197-202

@@ -94,8 +94,9 @@ def test_smpl_intermediates_and_exported_helpers(smpl_model):
     wj, wA = o.batch_global_rigid_transformation(Rs64, J64, np.asarray(smpl_model.parents))
     assert nj.shape == (B, 24, 3) and A4.shape == (B, 24, 4, 4)
     assert np.abs(nj.cpu().numpy() - wj).max() <= 1e-5 and np.abs(A4.cpu().numpy() - wA).max() <= 1e-5
-    with pytest.raises(NotImplementedError):
-        SMPLLayer.batch_global_rigid_transformation(t(Rs64), t(J64), smpl_model.parents, rotate_base=True)
+    nj, A4 = SMPLLayer.batch_global_rigid_transformation(t(Rs64), t(J64), smpl_model.parents, rotate_base=True)
+    wj, wA = o.batch_global_rigid_transformation(Rs64, J64, np.asarray(smpl_model.parents), rotate_base=True)
+    assert np.abs(nj.cpu().numpy() - wj).max() <= 1e-5 and np.abs(A4.cpu().numpy() - wA).max() <= 1e-5
 
 
 def test_config4_decoder_seg_and_silhouette_B128(smpl_model, part_tables):

@@ -271,3 +271,17 @@ def test_streaming_seg_equals_dense_autograd(smpl_model, part_tables):
     seg, dproj = to.seg_streaming_fwd_bwd(proj, mask, g, W, ids, off)
     assert torch.allclose(seg, dense.detach(), rtol=1e-12, atol=1e-300)
     assert torch.allclose(dproj, pd.grad, rtol=1e-9, atol=1e-14)
+
+
+def test_rotate_base_kat(smpl_model):
+    """rotate_base (batch_smpl.py:185-190): the root rotation times diag(1, -1, -1); every world transform of the tree
+    is that of the unrotated chain with its rotation part multiplied from the... root side: G'_i = G_0' G_0^-1 G_i, so
+    with theta = 0 (all R = I) the posed joints are the rest joints mirrored in y and z about the root joint."""
+    J = np.random.default_rng(0).normal(0, 0.3, (2, 24, 3))
+    Rs = np.tile(np.eye(3), (2, 24, 1, 1))
+    newJ, A = o.batch_global_rigid_transformation(Rs, J, np.asarray(smpl_model.parents), rotate_base=True)
+    want = J[:, :1] + (J - J[:, :1]) * np.array([1.0, -1.0, -1.0])
+    assert np.abs(newJ - want).max() < 1e-12
+    assert np.abs(A[:, :, :3, :3] - np.diag([1.0, -1.0, -1.0])).max() < 1e-12
+    newJ0, _ = o.batch_global_rigid_transformation(Rs, J, np.asarray(smpl_model.parents))
+    assert np.abs(newJ0 - J).max() < 1e-12
