@@ -50,3 +50,22 @@ def test_single_rank_default_needs_no_launcher():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.loads(r.stdout.decode().strip())
     assert d["n_gpus"] == 1 and d["rank_seeds"] == [1000]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_a_one_gpu_box():
+    """The real N = 2 path on hardware: `bench.py --gpus 2` starts two ranks itself, both on cuda:0 (local rank modulo
+    the device count), process group over gloo (RCCL needs a device per rank): HIP graph capture, barrier-bracketed
+    timing, MAX over ranks, one line with n_gpus = 2 and the whole-job rate."""
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-breakdown"],
+             env={"BENCH_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["config"]["meshes_per_gpu"] == 128
+    assert d["value"] > 0 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    assert "dry_run" not in d and d["config"]["launch"] in ("graph", "eager")
