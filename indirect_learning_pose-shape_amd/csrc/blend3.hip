@@ -214,12 +214,12 @@ __global__ __launch_bounds__(256) void blend3_fwd_kernel(const u32x4 *__restrict
 //   * a GEMM workgroup is 8 waves, two per SIMD: waves 0..3 multiply (one 32-mesh tile each, as in
 //     blend3_fwd_kernel), waves 4..7 PRODUCE their partners' operand - the coefficient rows [beta | Rs[1:] - I | 0] of
 //     the tile's 32 meshes, Rodrigues of two joints per mesh and step with the same `rodrigues()` as pose_fwd, into
-//     29 KB of LDS - and publish a step counter in LDS; the multiplying wave waits for the steps k-tile kt reads
-//     (coefficients 16 kt .. 16 kt + 15, i.e. joints <= 2 kt + 2 = steps 0..kt), reads its eight values and splits
-//     them into the three bf16 terms with the same `split8()` - the operand is the one pose_fwd would have written,
-//     bit for bit.  The producer's ~2 000 vector instructions issue beside the partner's MFMAs (a wave alone on a
-//     SIMD issues one vector instruction per 5 cycles whatever the matrix pipe does: computed by the multiplying
-//     wave itself they cost 6 us, in front of the loop or interleaved with it alike).
+//     29 KB of LDS, behind ONE workgroup barrier; the multiplying wave then reads its eight values per k-tile and
+//     splits them into the three bf16 terms with the same `split8()` - the operand is the one pose_fwd would have
+//     written, bit for bit.  The producer's ~2 000 vector instructions issue while the multipliers' first fragments
+//     of the constant are on their way (a wave alone on a SIMD issues one vector instruction per 5 cycles whatever
+//     the matrix pipe does: computed by the multiplying wave itself they cost 6 us, in front of the loop or
+//     interleaved with it alike).
 // Nothing is handed from workgroup to workgroup: the two roles write different outputs, and the chain's latency is
 // hidden under the GEMM on compute units the GEMM leaves idle (216 + 16 workgroups at B = 128 on 256 CUs).
 constexpr int FC_LD = 228;           // floats per mesh row of the staged coefficients (16-B aligned rows, bank-skewed)
@@ -232,7 +232,6 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
     const float *__restrict__ vt, int N3, int ntiles, int npose, float *__restrict__ Rs_out,
     float *__restrict__ J_out, float *__restrict__ A_out, float *__restrict__ newJ_out, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int s_step[4];                                 // GEMM role: coefficient steps published per mesh tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if ((int)blockIdx.x < npose) {                           // ---- role 1: pose_fwd for 8 meshes
@@ -243,15 +242,17 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
     return;
   }
   // ---- role 2: a 96-column tile of the GEMM for 4 x 32 meshes
-  if (tid < 4) s_step[tid] = 0;
-  __syncthreads();
   const int gb = blockIdx.x - npose;
   const int ct = gb % ntiles, grp = gb / ntiles;
   const int mw = wave & 3;                                  // mesh tile of this wave (multiplier w, producer w + 4)
   const int m0 = (grp * 4 + mw) * 32;
-  if (m0 >= B) return;                                      // this pair's mesh tile is empty (both waves leave)
+  const bool empty = m0 >= B;                               // this pair's mesh tile is empty: only the barrier to keep
   const int i = lane & 31, h = lane >> 5;
   float *sc = smem + mw * (32 * FC_LD);
+  if (empty) {
+    __syncthreads();
+    return;
+  }
   if (wave >= 4) {
     // ---- producer: lane (i, h) takes joint 2 s + 1 + h of mesh i in step s (rows beyond B repeat mesh B - 1)
     float th[12][3];
@@ -283,9 +284,15 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
         for (int e = 0; e < 9; ++e)
           sc[i * FC_LD + 10 + 9 * (j - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
       }
-      wave_sync();                                          // this wave's LDS writes have landed ...
-      if (lane == 0) __hip_atomic_store(&s_step[mw], st + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... publish
     }
+    // All rows are in LDS before any multiplier reads one: the workgroup barrier (which the multipliers join
+    // once their first fragments of the constant are requested) is the only hand-over.  A per-step counter in LDS
+    // with the multiplier starting on k-tile kt as soon as steps 0..kt were published was 1 us faster and WRONG about
+    // once in 30 launches - a tile of v_posed off by 1e-4, run-to-run (tools/probes/det_step.py) - with the
+    // stores drained (`s_waitcnt lgkmcnt(0)`) and even read back before the counter's store; a delay of 1 280 cycles
+    // before publishing made it disappear, waiting for two or three steps more made it rarer.  Not understood, so
+    // not used: nothing but `s_barrier` orders one wave's LDS stores before another wave's loads here.
+    __syncthreads();
     return;
   }
   // ---- multiplier
@@ -303,16 +310,13 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { hi[t][r] = 0.0f; lo[t][r] = 0.0f; }
   const float *arow = sc + i * FC_LD + 8 * h;
-  // the eight coefficients of k-tile kt for this lane, once the producer has published the steps it reads
+  // the eight coefficients of k-tile kt for this lane
 #define SMPLR_WAIT_READ(kt, x0_, x1_)                                                                       \
   {                                                                                                         \
-    const int need_ = (kt) + 1 < 12 ? (kt) + 1 : 12;                                                        \
-    while (__hip_atomic_load(&s_step[mw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need_)          \
-      __builtin_amdgcn_s_sleep(1);                                                                          \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                  \
     x0_ = *reinterpret_cast<const float4 *>(arow + 16 * (kt));                                              \
     x1_ = *reinterpret_cast<const float4 *>(arow + 16 * (kt) + 4);                                          \
   }
+  __syncthreads();                                          // the producers' rows are in LDS (their only hand-over)
   float4 x0, x1;
   SMPLR_WAIT_READ(0, x0, x1)
 #pragma unroll

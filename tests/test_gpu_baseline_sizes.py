@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from _inputs import make_x
-from test_gpu_parity import VERT_ATOL, SEG_RTOL, SEG_ATOL, grad_close, t
+from test_gpu_parity import VERT_ATOL, SEG_RTOL, SEG_ATOL, dev, grad_close, t
 
 pytestmark = pytest.mark.gpu
 
@@ -275,3 +275,97 @@ def test_deterministic_rasteriser_ops_and_scaling(layer_inputs=None):
             b = fn(c, True)
             grad_close((b / c).cpu().numpy(), a.cpu().numpy(), 1e-6, "%s cotangent x %g" % (name, c), per_column=False)
         assert float(fn(0.0, True).abs().max()) == 0.0
+
+
+def test_global_batch_1024_row_independence(smpl_model):
+    """configs[4]'s GLOBAL batch (1 024 meshes) on one GPU: eight 128-mesh groups of the blend GEMM, the 8-row form
+    of the segmentation backward (B >= 512), one silhouette workgroup per mesh: every row must equal the same row
+    computed in a batch of 32 (forward bit for bit, gradient to rounding), and the gradient must be finite."""
+    from ilps_amd.decoder import SMPLDecoder
+    W, B = 48, 1024
+    x = make_x(B, W, seed=1024)
+    rng = np.random.default_rng(10)
+    dec = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=True)
+    gs = t(rng.normal(0, 1, (B, W, W, 32)).astype(np.float32))
+    gl = t(rng.normal(0, 1, (B, W, W, 2)).astype(np.float32))
+    xg = t(x).requires_grad_(True)
+    out = dec(xg)
+    ((out["seg"] * gs).sum() + (out["silhouette"] * gl).sum()).backward()
+    assert torch.isfinite(xg.grad).all()
+    for lo in (0, 480, 992):
+        xs = t(x[lo:lo + 32]).requires_grad_(True)
+        o2 = dec(xs)
+        ((o2["seg"] * gs[lo:lo + 32]).sum() + (o2["silhouette"] * gl[lo:lo + 32]).sum()).backward()
+        for k in ("verts", "mask", "seg", "silhouette"):
+            assert torch.equal(o2[k], out[k][lo:lo + 32]), "%s rows %d.." % (k, lo)
+        grad_close(xg.grad[lo:lo + 32].cpu().numpy(), xs.grad.cpu().numpy(), 1e-4, "dx rows %d.." % lo)
+
+
+def test_decoder_step_replays_from_a_hip_graph(smpl_model):
+    """The decoder's forward + backward captured once in a HIP graph (what bench.py times) and replayed on NEW
+    parameter values written into the captured input buffer: outputs and gradient equal to the eager step's (the
+    launchers never allocate, synchronise or read host state that a capture would freeze)."""
+    from ilps_amd import ops
+    W, B = 48, 16
+    consts = ops.SMPLConstants.from_model(smpl_model, dev())
+    pt = ops.get_part_table(1, dev(), consts.V)
+    x_static = t(make_x(B, W, seed=1))
+    g = t(np.random.default_rng(2).normal(0, 1, (B, W, W, 32)).astype(np.float32))
+
+    def step(xin):
+        xg = xin.detach().requires_grad_(True)
+        verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1)
+        seg.backward(g)
+        return verts, seg, xg.grad
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step(x_static)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gv, gseg, gdx = step(x_static)
+    for seed in (5, 6):
+        xn = t(make_x(B, W, seed=seed))
+        x_static.copy_(xn)
+        graph.replay()
+        torch.cuda.synchronize()
+        ev, eseg, edx = step(xn)
+        assert torch.equal(gv, ev) and torch.equal(gseg, eseg)
+        grad_close(gdx.cpu().numpy(), edx.cpu().numpy(), 1e-5, "graph replay dx (seed %d)" % seed)
+
+
+def test_step_is_bit_reproducible_under_allocator_churn(smpl_model):
+    """200 decoder steps (both heads, deterministic backward) at B = 128 with other batch sizes and freed NaN-filled
+    buffers in between: every output and the gradient bit-identical to the first step's.  (A hand-over between two
+    waves of the fused pose + blend kernel through an LDS counter passed every parity test and was wrong about once
+    in 30 launches; this is the test that would have caught it.)"""
+    from ilps_amd import ops
+    W, B = 48, 128
+    consts = ops.SMPLConstants.from_model(smpl_model, dev())
+    pt = ops.get_part_table(1, dev(), consts.V)
+    x = t(make_x(B, W, seed=77))
+    rng = np.random.default_rng(3)
+    g = t(rng.normal(0, 1, (B, W, W, 32)).astype(np.float32))
+    gl = t(rng.normal(0, 1, (B, W, W, 2)).astype(np.float32))
+    names = ["verts", "proj", "mask", "seg", "silh", "Jt", "dx"]
+
+    def step(xin, gs, gsl):
+        xg = xin.detach().requires_grad_(True)
+        outs = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, True, 1, True)
+        torch.autograd.backward([outs[3], outs[4]], [gs, gsl])
+        return [o.detach().clone() for o in outs] + [xg.grad.clone()]
+
+    ref = step(x, g, gl)
+    for k in range(200):
+        if k % 5 == 0:
+            junk = [torch.full((1 << 22,), float("nan"), device=dev()) for _ in range(4)]
+            del junk
+        if k % 9 == 0:
+            step(x[:32], g[:32], gl[:32])
+        cur = step(x, g, gl)
+        for n, a, b in zip(names, cur, ref):
+            assert torch.equal(a, b), "run %d: %s differs at %d places" % (k, n, int((a != b).sum()))
