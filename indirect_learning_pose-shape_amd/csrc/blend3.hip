@@ -211,15 +211,15 @@ __global__ __launch_bounds__(256) void blend3_fwd_kernel(const u32x4 *__restrict
 // 10 us at B = 128 for 5 kFLOP per mesh - and the GEMM waited for it only because it read the coefficient
 // fragments that kernel wrote.  Here
 //   * the first ceil(B / 8) workgroups ARE pose_fwd (one wave per mesh: Rs, J, A, J_transformed), and
-//   * a GEMM workgroup is 8 waves, two per SIMD: waves 0..3 multiply (one 32-mesh tile each, as in
-//     blend3_fwd_kernel), waves 4..7 PRODUCE their partners' operand - the coefficient rows [beta | Rs[1:] - I | 0] of
-//     the tile's 32 meshes, Rodrigues of two joints per mesh and step with the same `rodrigues()` as pose_fwd, into
-//     29 KB of LDS, behind ONE workgroup barrier; the multiplying wave then reads its eight values per k-tile and
-//     splits them into the three bf16 terms with the same `split8()` - the operand is the one pose_fwd would have
-//     written, bit for bit.  The producer's ~2 000 vector instructions issue while the multipliers' first fragments
-//     of the constant are on their way (a wave alone on a SIMD issues one vector instruction per 5 cycles whatever
-//     the matrix pipe does: computed by the multiplying wave itself they cost 6 us, in front of the loop or
-//     interleaved with it alike).
+//   * a GEMM workgroup is 8 waves, two per SIMD.  Phase 1, all eight: the coefficient rows [beta | Rs[1:] - I | 0] of
+//     the workgroup's 4 x 32 meshes into 29 KB of LDS per mesh tile - Rodrigues of two joints per mesh and step with
+//     the same `rodrigues()` as pose_fwd, six steps per wave (wave w and its partner w + 4 share tile w), wave w having
+//     requested its first fragments of the constant beforehand.  ONE workgroup barrier.  Phase 2, waves 0..3 (the
+//     others leave): the GEMM tile as in blend3_fwd_kernel, each k-tile's eight values per lane read from LDS and
+//     split into the three bf16 terms with the same `split8()` - the operand is the one pose_fwd would have
+//     written, bit for bit.  (A wave alone on a SIMD issues one vector instruction per 5 cycles whatever the matrix
+//     pipe does: the ~2 000 vector instructions of a tile's rows cost 6 us on the multiplying wave alone, in front
+//     of the loop or interleaved with it alike; on two waves per SIMD in front of the barrier about 2.)
 // Nothing is handed from workgroup to workgroup: the two roles write different outputs, and the chain's latency is
 // hidden under the GEMM on compute units the GEMM leaves idle (216 + 16 workgroups at B = 128 on 256 CUs).
 constexpr int FC_LD = 228;           // floats per mesh row of the staged coefficients (16-B aligned rows, bank-skewed)
@@ -253,57 +253,63 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
     __syncthreads();
     return;
   }
-  if (wave >= 4) {
-    // ---- producer: lane (i, h) takes joint 2 s + 1 + h of mesh i in step s (rows beyond B repeat mesh B - 1)
-    float th[12][3];
+  // ---- phase 1, all eight waves: the coefficient rows.  Lane (i, h) takes joint 2 s + 1 + h of mesh i in step s; the
+  // multiplier wave w does steps 0..5 of its tile (after requesting its first fragments of the constant), its
+  // partner w + 4 steps 6..11 and the betas / padding (rows beyond B repeat mesh B - 1)
+  const int c = ct * F3_BN + 3 * i;
+  const u32x4 *bp = pk + (size_t)ct * (NKT * 9 * 64) + lane;
+  u32x4 b[F3F_DEPTH + 1][9];
+#define SMPLR_LOAD_B(slot, kt) \
+  { _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) b[slot][j_] = bp[((kt) * 9 + j_) * 64]; }
+  if (wave < 4) {
 #pragma unroll
-    for (int st = 0; st < 12; ++st) {
-      const int j = min(2 * st + 1 + h, 23);
+    for (int kt = 0; kt < F3F_DEPTH; ++kt) { SMPLR_LOAD_B(kt % (F3F_DEPTH + 1), kt) }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const int s0 = wave < 4 ? 0 : 6;
+    float th[6][3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int j = min(2 * (s0 + q) + 1 + h, 23);
       const float *xr = x + (size_t)min(m0 + i, B - 1) * x_stride + num_cam + 3 * j;
-      th[st][0] = xr[0]; th[st][1] = xr[1]; th[st][2] = xr[2];
+      th[q][0] = xr[0]; th[q][1] = xr[1]; th[q][2] = xr[2];
     }
-    float be[5];
+    if (wave >= 4) {
+      float be[5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int e = lane + 64 * t, mi = e / 10, k = e - 10 * mi;
-      be[t] = x[(size_t)min(m0 + mi, B - 1) * x_stride + num_cam + 72 + k];
+      for (int t = 0; t < 5; ++t) {
+        const int e = lane + 64 * t, mi = e / 10, k = e - 10 * mi;
+        be[t] = x[(size_t)min(m0 + mi, B - 1) * x_stride + num_cam + 72 + k];
+      }
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int e = lane + 64 * t, mi = e / 10, k = e - 10 * mi;
+        sc[mi * FC_LD + k] = be[t];
+      }
+      for (int e = lane; e < 32 * 7; e += 64) sc[(e / 7) * FC_LD + 217 + e % 7] = 0.0f;       // 217..223
     }
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-      const int e = lane + 64 * t, mi = e / 10, k = e - 10 * mi;
-      sc[mi * FC_LD + k] = be[t];
-    }
-    for (int e = lane; e < 32 * 7; e += 64) sc[(e / 7) * FC_LD + 217 + e % 7] = 0.0f;       // 217..223
-#pragma unroll
-    for (int st = 0; st < 12; ++st) {
-      const int j = 2 * st + 1 + h;
+    for (int q = 0; q < 6; ++q) {
+      const int j = 2 * (s0 + q) + 1 + h;
       float R[9];
-      rodrigues(th[st], R);
+      rodrigues(th[q], R);
       if (j <= 23) {
 #pragma unroll
         for (int e = 0; e < 9; ++e)
           sc[i * FC_LD + 10 + 9 * (j - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
       }
     }
-    // All rows are in LDS before any multiplier reads one: the workgroup barrier (which the multipliers join
-    // once their first fragments of the constant are requested) is the only hand-over.  A per-step counter in LDS
-    // with the multiplier starting on k-tile kt as soon as steps 0..kt were published was 1 us faster and WRONG about
-    // once in 30 launches - a tile of v_posed off by 1e-4, run-to-run (tools/probes/det_step.py) - with the
-    // stores drained (`s_waitcnt lgkmcnt(0)`) and even read back before the counter's store; a delay of 1 280 cycles
-    // before publishing made it disappear, waiting for two or three steps more made it rarer.  Not understood, so
-    // not used: nothing but `s_barrier` orders one wave's LDS stores before another wave's loads here.
-    __syncthreads();
-    return;
   }
-  // ---- multiplier
-  const int c = ct * F3_BN + 3 * i;
-  const u32x4 *bp = pk + (size_t)ct * (NKT * 9 * 64) + lane;
-  u32x4 b[F3F_DEPTH + 1][9];
-#define SMPLR_LOAD_B(slot, kt) \
-  { _Pragma("unroll") for (int j_ = 0; j_ < 9; ++j_) b[slot][j_] = bp[((kt) * 9 + j_) * 64]; }
-#pragma unroll
-  for (int kt = 0; kt < F3F_DEPTH; ++kt) { SMPLR_LOAD_B(kt % (F3F_DEPTH + 1), kt) }
-  __builtin_amdgcn_sched_barrier(0);
+  // All rows are in LDS before any multiplier reads one: the workgroup barrier is the only hand-over.  A per-step
+  // counter in LDS with the multiplier starting on k-tile kt as soon as steps 0..kt were published was WRONG about
+  // once in 30 launches - a tile of v_posed off by 1e-4, run-to-run (tools/probes/det_step.py) - with the stores
+  // drained (`s_waitcnt lgkmcnt(0)`) and even read back before the counter's store; a delay of 1 280 cycles before
+  // publishing made it disappear, waiting for two or three steps more made it rarer.  Not understood, so not
+  // used: nothing but `s_barrier` orders one wave's LDS stores before another wave's loads here.
+  __syncthreads();
+  if (wave >= 4) return;
+  // ---- phase 2, waves 0..3: multiply
   f32x16 hi[3], lo[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
@@ -316,7 +322,6 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
     x0_ = *reinterpret_cast<const float4 *>(arow + 16 * (kt));                                              \
     x1_ = *reinterpret_cast<const float4 *>(arow + 16 * (kt) + 4);                                          \
   }
-  __syncthreads();                                          // the producers' rows are in LDS (their only hand-over)
   float4 x0, x1;
   SMPLR_WAIT_READ(0, x0, x1)
 #pragma unroll
