@@ -791,11 +791,12 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
 // (SB_SLOTS = 4096 accumulators per window, SB_NWIN = 5 windows, 8 or 24 rows per block by batch size: common.h)
 constexpr int SB_U = 8;          // pixels in flight per lane
 
+// (unconditional: a run that ends has a non-zero sum except by cancellation, and the walk starts on slot 0 with a sum
+// of zero, so the tests that used to guard this - slot valid, sum non-zero - only cost their instructions, in a kernel
+// whose SIMDs are 88 % busy issuing)
 __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float sy) {
-  if (cur >= 0 && (sx != 0.0f || sy != 0.0f)) {
-    atomicAdd(&acc[cur * 2], sx);
-    atomicAdd(&acc[cur * 2 + 1], sy);
-  }
+  atomicAdd(&acc[cur * 2], sx);
+  atomicAdd(&acc[cur * 2 + 1], sy);
 }
 
 // Deterministic form: the run sums are added as 64-bit fixed-point integers (ds_add_u64).  Integer addition is
@@ -804,10 +805,8 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
 // largest record weight, see seg_bwd_kernel) keeps 2^-41 of the largest possible term as the resolution, far
 // below an fp32 sum's own rounding.
 __device__ __forceinline__ void seg_flush_det(unsigned long long *acc, int cur, float sx, float sy, float scale) {
-  if (cur >= 0 && (sx != 0.0f || sy != 0.0f)) {
-    atomicAdd(&acc[cur * 2], (unsigned long long)__float2ll_rn(sx * scale));
-    atomicAdd(&acc[cur * 2 + 1], (unsigned long long)__float2ll_rn(sy * scale));
-  }
+  atomicAdd(&acc[cur * 2], (unsigned long long)__float2ll_rn(sx * scale));
+  atomicAdd(&acc[cur * 2 + 1], (unsigned long long)__float2ll_rn(sy * scale));
 }
 
 // One row strip (a 32-lane group, lane = channel) over its W pixels for one slot window.  MW =
@@ -820,7 +819,8 @@ __device__ __forceinline__ void seg_flush_det(unsigned long long *acc, int cur, 
 template <bool MW, bool FAST, bool DET>
 __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, const short *__restrict__ arg,
                                             const float4 *__restrict__ R, int rbytes, float *acc, size_t row0,
-                                            int W, int C, int ch, float fr, int base, float scale) {
+                                            int W, int C, int ch, float fr, int base, float scale,
+                                            const int *pa, const float *pg) {
   unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
   const int chc = FAST ? ch : min(ch, C - 1);
   const bool chok = ch >= 1 && ch < C;
@@ -828,7 +828,7 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(R), 0, rbytes, 0x00020000);
   const short *arow = arg + row0 * 32 + ch;                    // FAST: + 32 (c0 + u) shorts
   const float *grow = dseg + row0 * 32 + ch;                   // FAST (C == 32): + 32 (c0 + u) floats
-  int cur = -1;
+  int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
   float sx = 0.0f, sy = 0.0f;
   for (int c0 = 0; c0 < W; c0 += SB_U) {
     int a[SB_U];
@@ -838,8 +838,13 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       const float *gb = grow + c0 * 32;
 #pragma unroll
       for (int u = 0; u < SB_U; ++u) {
-        a[u] = ab[u * 32];
-        g[u] = gb[u * 32];
+        if (c0 == 0) {                            // (uniform) the first batch was requested at kernel entry
+          a[u] = pa[u];
+          g[u] = pg[u];
+        } else {
+          a[u] = ab[u * 32];
+          g[u] = gb[u * 32];
+        }
       }
     } else {
 #pragma unroll
@@ -853,10 +858,10 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
     float4 rv[SB_U];
 #pragma unroll
     for (int u = 0; u < SB_U; ++u) {
-      const int gate = __shfl(a[u], 0, 32);       // channel-0 lane of this pixel: 1 = clip passes gradient
-      const float g0 = __shfl(g[u], 0, 32);
-      g[u] = g[u] - ((gate == 1) ? g0 : 0.0f);
-      if (!(chok && (FAST || c0 + u < W))) a[u] = -1;
+      // the channel-0 lane of this pixel holds the clip's gate (1 = the background's gradient passes) and that
+      // gradient: what every channel subtracts is selected there and broadcast once
+      g[u] = g[u] - __shfl((a[u] == 1) ? g[u] : 0.0f, 0, 32);
+      if (!FAST && !(chok && c0 + u < W)) a[u] = -1;
       if (MW) {
         a[u] -= base;                             // another window's slot -> masked
         if (a[u] >= SB_SLOTS) a[u] = -1;
@@ -865,16 +870,23 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       // the descriptor's range and reads as zeros (kk = 0 below) - no clamp, no 64-bit address per gather
       rv[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (base + a[u]) * 16, 0, 0));
     }
+    if (FAST && !chok) continue;                  // channel 0 has no part (its lanes have served the broadcast above)
 #pragma unroll
     for (int u = 0; u < SB_U; ++u) {
       const float fc = (float)(c0 + u);
       const float du = rv[u].x - fc, dv = rv[u].y - fr;
       const float d2 = fmaf(du, du, dv * dv);
-      const float x = fast_sqrt(d2 * rv[u].z);    // m * d, as the forward computed it
-      // d score / d(u,v) = -score * m * (p - q) / d = -score * x * (p - q) / d^2
-      const float k = -g[u] * fast_exp_neg(x) * x;
-      const bool on = a[u] >= 0 && d2 > 0.0f && k != 0.0f;
-      const float kk = on ? k * __builtin_amdgcn_rcpf(d2) : 0.0f;
+      // d score / d(u,v) = -score m (p - q) / d, score = exp(-m d).  With t = (m d)^2 and r = 1 / sqrt(t): m d = t r
+      // and m / d = m^2 r - two transcendental instructions per pixel (v_rsq, v_exp) instead of three (v_sqrt, v_exp,
+      // v_rcp): they issue at a quarter of the rate and were a third of the vector time of this vector-bound loop.
+      // d = 0: t is lifted to 1e-37, kk is large but finite and multiplies du = dv = 0: the gradient is 0, not NaN.
+      const float t = d2 * rv[u].z;
+      const float r = __builtin_amdgcn_rsqf(fmaxf(t, 1e-37f));
+      float kk = (-g[u] * fast_exp_neg(t * r)) * (rv[u].z * r);
+      // kk != 0 says it all: a masked slot (-1) read a record of zeros (m^2 = 0); exp underflows beyond 104
+      // (with slot windows a slot below the window is a valid record of another window: tested there)
+      if (MW && a[u] < 0) kk = 0.0f;
+      const bool on = kk != 0.0f;
       if (on && a[u] != cur) {
         if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
         else seg_flush(acc, cur, sx, sy);
@@ -903,6 +915,29 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
   const int n = blockIdx.y, tid = threadIdx.x, nthr = 32 * rows;   // a 32-lane group per row of the block
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
+  const int C = P + 1, npix = W * W;
+  const int ch = tid & 31, strip = tid >> 5;
+  // Output (flipped) row of this strip.  Rows across the body end more runs (flushes) than rows of background, and a
+  // workgroup waits for its slowest wave, the launch for its slowest workgroup: the row blocks of a mesh take
+  // interleaved rows, and the two strips of a wave an early and a late one of the block's.
+  const int kidx = (strip & 1) ? rows - 1 - (strip >> 1) : (strip >> 1);
+  const int ro = blockIdx.x + gridDim.x * kidx;
+  const float fr = (float)(W - 1 - ro);
+  const size_t row0 = (size_t)n * npix + (size_t)ro * W;
+  const bool fast = C == 32 && W % SB_U == 0;               // block-uniform
+  // The first batch of the row walk is requested here, behind the header: its trip to HBM (2 us at the head of a
+  // 20 us kernel that otherwise streams at 4.8 TB/s) then runs under the zeroing of the accumulators and its barrier.
+  int pa[SB_U];
+  float pg[SB_U];
+#pragma unroll
+  for (int u = 0; u < SB_U; ++u) { pa[u] = 0; pg[u] = 0.0f; }
+  if (fast && ro < W) {
+#pragma unroll
+    for (int u = 0; u < SB_U; ++u) {
+      pa[u] = arg[(row0 + u) * 32 + ch];
+      pg[u] = dseg[(row0 + u) * 32 + ch];
+    }
+  }
   if (dproj) {                                                // (NULL: the consumer gathers the slot sums itself)
     // this block's share of the mesh's dproj rows := 0 (the merge kernel then stores the sums)
     float *dp = dproj + (size_t)n * VP * 3;
@@ -910,11 +945,6 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     const int z0 = blockIdx.x * per, z1 = min(tot, z0 + per);
     for (int i = z0 + tid; i < z1; i += nthr) dp[i] = 0.0f;
   }
-  const int C = P + 1, npix = W * W;
-  const int ch = tid & 31, strip = tid >> 5;
-  const int ro = blockIdx.x * rows + strip;            // output (flipped) row of this strip
-  const float fr = (float)(W - 1 - ro);
-  const size_t row0 = (size_t)n * npix + (size_t)ro * W;
   float scale = 1.0f, inv_scale = 1.0f;
   if (DET) {
     // Bound of one term: |g - g0| m |du| / d <= 2 max|dseg| max(m); a slot collects at most rows x W of them.
@@ -948,10 +978,14 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     else for (int i = tid; i < nsl * 2; i += nthr) acc[i] = 0.0f;
     __syncthreads();
     if (ro < W) {
-      const bool fast = C == 32 && W % SB_U == 0;           // block-uniform
-      if (nwin == 1 && fast) seg_bwd_row<false, true, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale);
-      else if (nwin == 1) seg_bwd_row<false, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale);
-      else seg_bwd_row<true, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale);
+      // (the compiler would otherwise start on the first batch - and wait for it - in front of the barrier)
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) asm volatile("" : "+v"(pa[u]), "+v"(pg[u]));
+      if (nwin == 1 && fast)
+        seg_bwd_row<false, true, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
+      else if (nwin == 1)
+        seg_bwd_row<false, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
+      else seg_bwd_row<true, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale, pa, pg);
     }
     __syncthreads();
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);

@@ -1,5 +1,6 @@
 #!/bin/bash
-# bash tools/ab_kernel.sh KERNEL_SUBSTRING lib1 lib2 ...: rocprofv3 average of one kernel of the eager bench step under each library build
+# bash tools/ab_kernel.sh KERNEL_SUBSTRING[,SUBSTRING...] lib1 lib2 ...: rocprofv3 average of the named kernels of the eager bench step
+# under each library build (indirect_learning_pose-shape_amd/lib_<name>.so)
 cd "$GRAFT_REPO_ROOT"; PKG=indirect_learning_pose-shape_amd; K=$1; shift
 cp $PKG/libsmplraster_hip.so $PKG/lib_keep.so
 for v in "$@"; do
@@ -9,7 +10,7 @@ for v in "$@"; do
 import csv,glob
 f=glob.glob('gpurun_out/abk_$v/*/*_kernel_stats.csv')[0]
 for r in csv.DictReader(open(f)):
-    if '$K' in r['Name']: print('$v', r['Name'][:40], 'avg %.2f us' % (float(r['AverageNs'])/1e3))
+    if any(k in r['Name'] for k in '$K'.split(',')): print('$v', r['Name'][:40], 'avg %.2f us' % (float(r['AverageNs'])/1e3))
 "
 done
 cp $PKG/lib_keep.so $PKG/libsmplraster_hip.so
