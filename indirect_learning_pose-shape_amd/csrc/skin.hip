@@ -105,13 +105,15 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
   }
 }
 
+// (7 waves per SIMD: 3456 workgroups of 4 waves at B = 128 are then 1.93 rounds of the 1792 that fit, not 2.25 of 1536;
+// needs <= 72 registers: 65 with T built row by row)
 // One block = 256 vertices x SKB_MB meshes (the 24 skinning weights of a vertex are loaded once and
 // kept in registers / LDS for all of them).  part layout per (mesh, block): 288 dA + 4 dcam floats.
 constexpr int SKB_PART = 292;
 constexpr int SKB_MB = 1;
 
 template <bool SPARSE>
-__global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) void skin_bwd_kernel(
+__global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 7 : 4, 8))) void skin_bwd_kernel(
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
     const float *__restrict__ lbs, const float *__restrict__ top4, const float *__restrict__ A,
     const float *__restrict__ cam,
@@ -206,51 +208,52 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
     // T = sum_j w_j A_j with the mesh's joint matrix staged in LDS (broadcast ds_read_b128) and
     // w_j taken from LDS as well: as scalar operands the 288 matrix entries need more SGPRs than
     // exist (the compiler then spills through v_readlane or falls back to 288 vector loads).
-    float T[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.0f;
-#pragma unroll
-    for (int jq = 0; jq < (SPARSE ? 4 : 24); ++jq) {
-      const int j = SPARSE ? jx[jq & 3] : jq;
-      const float wj = SPARSE ? w4[jq & 3] : w[SPARSE ? 0 : jq];
-      const float4 r0 = sAj[j * 3], r1 = sAj[j * 3 + 1], r2 = sAj[j * 3 + 2];
-      T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
-      T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
-      T[8] = fmaf(wj, r2.x, T[8]); T[9] = fmaf(wj, r2.y, T[9]); T[10] = fmaf(wj, r2.z, T[10]); T[11] = fmaf(wj, r2.w, T[11]);
-    }
-
+    // ... one ROW of T at a time (4 live values instead of 12: the kernel's register peak was here, and 72 registers
+    // are what a seventh wave per SIMD needs): row r gives dv_posed its g_r terms, rows 0 and 1 the projected X and Y
+    const bool proj_on = live && has_proj && sampled;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
     float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
-    if (live) {
-      g0 = gv0; g1 = gv1; g2 = gv2;
-      if (has_proj && sampled) {
-        const float du = gp0, dv = gp1;
-        const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
-        const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
-        g0 += ck0 * du; g1 += ck1 * dv; g2 += gp2;
-        dku = X * du; dkv = Y * dv; du0 = du; dv0 = dv;
+    if (live) { g0 = gv0; g1 = gv1; g2 = gv2; }
+    // (explicit fmas: the sparse and the dense instantiation must round alike, whatever the compiler would contract)
+    if (proj_on) { g0 = fmaf(ck0, gp0, g0); g1 = fmaf(ck1, gp1, g1); g2 += gp2; du0 = gp0; dv0 = gp1; }
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int jq = 0; jq < (SPARSE ? 4 : 24); ++jq) {
+        const int j = SPARSE ? jx[jq & 3] : jq;
+        const float wj = SPARSE ? w4[jq & 3] : w[SPARSE ? 0 : jq];
+        const float4 rr = sAj[j * 3 + r];
+        t0 = fmaf(wj, rr.x, t0); t1 = fmaf(wj, rr.y, t1); t2 = fmaf(wj, rr.z, t2); t3 = fmaf(wj, rr.w, t3);
       }
+      const float gr = r == 0 ? g0 : (r == 1 ? g1 : g2);
+      dp0 = fmaf(t0, gr, dp0); dp1 = fmaf(t1, gr, dp1); dp2 = fmaf(t2, gr, dp2);
+      if (r < 2 && proj_on) {
+        const float XY = fmaf(t2, p2, fmaf(t1, p1, fmaf(t0, p0, t3)));
+        if (r == 0) dku = XY * gp0; else dkv = XY * gp1;
+      }
+    }
+    if (live) {
       float *o = dv_posed + ((size_t)n * V + v) * 3;
-      o[0] = T[0] * g0 + T[4] * g1 + T[8] * g2;
-      o[1] = T[1] * g0 + T[5] * g1 + T[9] * g2;
-      o[2] = T[2] * g0 + T[6] * g1 + T[10] * g2;
+      o[0] = dp0; o[1] = dp1; o[2] = dp2;
     }
     // A operand of the dA product, straight from the (L2-resident) weight table in MFMA layout:
     // lane (li, lk) of step s holds w[vertex 64 wave + 4 s + lk][joint li] and [joint 16 + li]
     // (4 rows x 64-B segments per load); 32 loads per wave, requested once T is done (their latency
     // overlaps the barrier; asked for at the top they cost 32 live registers = one wave per SIMD).
-    float wa0[16], wa1[16];
+    float wa0[8], wa1[8];        // a ring of 8 steps: steps 8..15 are requested as the first eight are consumed
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
+    const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
+    const int o0 = (vb * 24 + li) * 4, o1 = (vb * 24 + 16 + (li & 7)) * 4;
     {
       // buffer loads: a 128-bit descriptor of the weight table (wave-uniform) + ONE 32-bit byte offset per lane
       // + an immediate per step, rows past the end of the table read as 0 (the hardware's range check; their
       // vertices carry g = 0 anyway) - instead of a clamp and a 64-bit multiply-add per request (a fifth of
       // the kernel's vector instructions)
-      const __amdgpu_buffer_rsrc_t rs =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
-      const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
-      const int o0 = (vb * 24 + li) * 4, o1 = (vb * 24 + 16 + (li & 7)) * 4;
   #pragma unroll
-      for (int sI = 0; sI < 16; ++sI) {
+      for (int sI = 0; sI < 8; ++sI) {
         wa0[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o0 + sI * 384, 0, 0));
         wa1[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o1 + sI * 384, 0, 0));
       }
@@ -264,11 +267,15 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(6, 8))) v
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int t = wave * 64 + s * 4 + lk;     // tail vertices carry g = 0 and finite (clamped) weights
-      const float a0 = wa0[s];
-      const float a1 = (li < 8) ? wa1[s] : 0.0f;
+      const float a0 = wa0[s & 7];
+      const float a1 = (li < 8) ? wa1[s & 7] : 0.0f;
       const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+      if (s < 8) {
+        wa0[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o0 + (s + 8) * 384, 0, 0));
+        wa1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o1 + (s + 8) * 384, 0, 0));
+      }
     }
     // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
     if (li < 12) {
