@@ -40,6 +40,41 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int WAVE = 64;
 
+// In-kernel timelines (tools/probes/*_timeline.py).  Built with -DSMPLR_TL (make CXXFLAGS+=-DSMPLR_TL) a kernel that
+// declares SMPLR_TL_WAVE(buffer, waves-per-workgroup, workgroup) has one lane per wave stamp the shader clock into a
+// __device__ buffer (32 words per wave: 0 = entry, 28 = the 100 MHz wall clock, 29 = HW_ID, 30 = XCC_ID) at every
+// SMPLR_TL_STAMP(i), and the library exports smplr_tl_read_<kernel>().  Without the flag all of it compiles to nothing.
+#ifdef SMPLR_TL
+#define SMPLR_TL_WAVE(buf, nwaves, wg, nwg)                                                                       \
+  unsigned *tl__ = ((threadIdx.x & 63) == 1 && (wg) < (nwg)) ? (buf) + ((size_t)(wg) * (nwaves) + (threadIdx.x >> 6)) * 32 \
+                                                             : nullptr;                                           \
+  if (tl__) {                                                                                                     \
+    tl__[0] = (unsigned)clock64();                                                                                \
+    tl__[28] = (unsigned)wall_clock64();                                                                          \
+    tl__[29] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));                                              \
+    tl__[30] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));                                             \
+  }
+#define SMPLR_TL_PTR(buf, nwaves, wg, nwg)                                                                        \
+  unsigned *tl__ = ((threadIdx.x & 63) == 1 && (wg) < (nwg)) ? (buf) + ((size_t)(wg) * (nwaves) + (threadIdx.x >> 6)) * 32 \
+                                                             : nullptr;
+#define SMPLR_TL_STAMP(i)                        \
+  do {                                           \
+    if (tl__) tl__[i] = (unsigned)clock64();     \
+  } while (0)
+#define SMPLR_TL_EXPORT(name, buf, words)                                                                \
+  extern "C" int smplr_tl_read_##name(unsigned *host, int n) {                                           \
+    if (n > (words)) n = (words);                                                                        \
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(buf), (size_t)n * 4, 0, hipMemcpyDeviceToHost);     \
+  }
+#else
+#define SMPLR_TL_WAVE(buf, nwaves, wg, nwg)
+#define SMPLR_TL_PTR(buf, nwaves, wg, nwg)
+#define SMPLR_TL_STAMP(i) \
+  do {                    \
+  } while (0)
+#define SMPLR_TL_EXPORT(name, buf, words)
+#endif
+
 // Internal pieces of the fused SMPL backward (smplr_smpl_bwd, pose.hip): the partial-sum producers
 // without their stand-alone reduction kernels.
 struct BlendBwdGeom { int nslices, cols_per_block, nmt; size_t part_floats; };

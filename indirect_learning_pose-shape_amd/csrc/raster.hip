@@ -42,6 +42,11 @@ constexpr float X_ZERO = 104.0f;     // expf(-x) rounds to 0 in fp32 for x >= 10
 constexpr float M_LOCAL = 208.0f;    // m > 208 => 104/m < 0.5 px: only the nearest pixel centre
 constexpr int GP = 4;                // global-list group size (padding granule)
 constexpr int BIN_T = 1024;
+#ifdef SMPLR_TL
+constexpr int TL_BIN_WG = 128, TL_SEGBWD_WG = 256;
+__device__ unsigned g_tl_bin[TL_BIN_WG * (BIN_T / 64) * 32];
+__device__ unsigned g_tl_segbwd[TL_SEGBWD_WG * 12 * 32];
+#endif
 constexpr int IPT_MAX = 8;           // part-table slots per bin thread: K <= 8192
 
 // ------------------------------------------------------------------------------------------------
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64], s_gb[BIN_T];
   __shared__ int s_any_empty, s_nonunit;
   const int n = blockIdx.x, tid = threadIdx.x;
+  SMPLR_TL_WAVE(g_tl_bin, BIN_T / 64, n, TL_BIN_WG)
   const int npix = W * W;
   const float *pj = proj + (size_t)n * VP * 3;
   float *mk = mask + (size_t)n * VP;
@@ -157,7 +163,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
     for (int i = tid; i < words; i += BIN_T) vis[i] = 0u;
   }
+  SMPLR_TL_STAMP(1);
   __syncthreads();
+  SMPLR_TL_STAMP(2);
   if (VIS || STAGE) {
     const float fG = (float)vgrid;
     for (int base = 0; base < VP; base += VPT * BIN_T) {
@@ -188,7 +196,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
         }
       }
     }
+    SMPLR_TL_STAMP(3);
     __syncthreads();
+    SMPLR_TL_STAMP(4);
   }
   bool vertex1 = false;                          // an empty cell makes vertex 1 visible (compute_mask.py:99)
   if (VIS) {
@@ -203,11 +213,14 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       }
     }
     if (empty) s_any_empty = 1;   // benign same-value race
+    SMPLR_TL_STAMP(5);
     __syncthreads();
+    SMPLR_TL_STAMP(6);
     vertex1 = s_any_empty && ref_compat && VP > 1;
     for (int v = tid; v < VP; v += BIN_T)
       mk[v] = (((vis[v >> 5] >> (v & 31)) & 1u) || (vertex1 && v == 1)) ? 1.0f : 500.0f;
   }
+  SMPLR_TL_STAMP(7);
   float4 *Gn = G + (size_t)n * S;
   int *goffn = goff + (size_t)n * (P + 2);
   int *lstartn = lstart + (size_t)n * (npix + 1);
@@ -246,7 +259,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
     p0 = lo;
   }
+  SMPLR_TL_STAMP(8);
   __syncthreads();                               // pixel counters complete
+  SMPLR_TL_STAMP(9);
   // ONE block scan for both prefixes: global records per thread (low half) and local records per thread's
   // pixel range (high half); K <= 8192 keeps either total below 2^16
   const int ept = (npix + BIN_T - 1) / BIN_T;
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   int tot2;
   const int base2 = block_excl_scan(gcnt | (loc << 16), s_wave, &tot2);
   const int gbase = base2 & 0xffff, gtotal = tot2 & 0xffff, ltotal = tot2 >> 16;
+  SMPLR_TL_STAMP(10);
   s_gb[tid] = gbase | (int)(gbits << 16);
   {
     int run = base2 >> 16;                       // counting sort offsets over pixels
@@ -267,7 +283,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
     if (tid == 0) lstartn[npix] = ltotal;
   }
+  SMPLR_TL_STAMP(11);
   __syncthreads();
+  SMPLR_TL_STAMP(12);
   if (tid < 64) {
     // global prefix at each part's first slot: the owning thread's base + its global flags below that slot
     // (empty parts share a slot; parts that start at K take the total); then the padded part offsets (P <= 31)
@@ -292,7 +310,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       goffn[tid] = inc - cnt;
     }
   }
+  SMPLR_TL_STAMP(13);
   __syncthreads();
+  SMPLR_TL_STAMP(14);
   // pass 3: placement
   {
     int p = p0;
@@ -316,6 +336,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       }
     }
   }
+  SMPLR_TL_STAMP(15);
   // header: used slots | 1 if some far-reaching record has a weight other than 1 (else the pair loop skips m^2)
   if (tid == 0) goffn[P + 1] = s_nonunit;
   if (tid == 0)
@@ -326,11 +347,14 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     for (int i = s_gpad[tid] + cnt; i < s_gpad[tid + 1]; ++i)
       Gn[i] = make_float4(INFINITY, INFINITY, 1.0f, __int_as_float(-1));
   }
+  SMPLR_TL_STAMP(16);
   if (vslot) {                                                // block-uniform
     __syncthreads();
+    SMPLR_TL_STAMP(17);
     short *vo = vslot + (size_t)n * VP;
     for (int i = tid; i < VP; i += BIN_T) vo[i] = sSlot[i];
   }
+  SMPLR_TL_STAMP(18);
 }
 
 __device__ __forceinline__ float pair_key(const float4 a, float fc, float fr) {
@@ -816,6 +840,11 @@ __device__ __forceinline__ void seg_flush_det(unsigned long long *acc, int cur, 
 // sit at compile-time byte offsets (128 B / 64 B per pixel) from ONE address per lane and batch - the general
 // form spent 29 % of the kernel's vector instructions on 64-bit address arithmetic, in a kernel that is
 // vector-issue bound.
+#ifdef SMPLR_TL
+#define SMPLR_TL_ROW SMPLR_TL_PTR(g_tl_segbwd, 12, blockIdx.y * gridDim.x + blockIdx.x, (W <= 80 ? TL_SEGBWD_WG : 0))
+#else
+#define SMPLR_TL_ROW
+#endif
 template <bool MW, bool FAST, bool DET>
 __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, const short *__restrict__ arg,
                                             const float4 *__restrict__ R, int rbytes, float *acc, size_t row0,
@@ -830,6 +859,7 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
   const float *grow = dseg + row0 * 32 + ch;                   // FAST (C == 32): + 32 (c0 + u) floats
   int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
   float sx = 0.0f, sy = 0.0f;
+  SMPLR_TL_ROW
   for (int c0 = 0; c0 < W; c0 += SB_U) {
     int a[SB_U];
     float g[SB_U];
@@ -870,6 +900,7 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       // the descriptor's range and reads as zeros (kk = 0 below) - no clamp, no 64-bit address per gather
       rv[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (base + a[u]) * 16, 0, 0));
     }
+    SMPLR_TL_STAMP(3 + c0 / SB_U * 2);           // (batches 0..9: words 3..22)
     if (FAST && !chok) continue;                  // channel 0 has no part (its lanes have served the broadcast above)
 #pragma unroll
     for (int u = 0; u < SB_U; ++u) {
@@ -897,6 +928,7 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
       sx = fmaf(kk, du, sx);
       sy = fmaf(kk, dv, sy);
     }
+    SMPLR_TL_STAMP(4 + c0 / SB_U * 2);
   }
   if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
   else seg_flush(acc, cur, sx, sy);
@@ -913,6 +945,7 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
   unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
   __shared__ unsigned s_gmax, s_m2max;
   const int n = blockIdx.y, tid = threadIdx.x, nthr = 32 * rows;   // a 32-lane group per row of the block
+  SMPLR_TL_WAVE(g_tl_segbwd, 12, blockIdx.y * gridDim.x + blockIdx.x, (W <= 80 ? TL_SEGBWD_WG : 0))
   const float4 *R = rec + (size_t)n * S;
   const int nslots = __float_as_int(R[S - 1].x);
   const int C = P + 1, npix = W * W;
@@ -969,6 +1002,7 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     scale = ldexpf(1.0f, e);
     inv_scale = ldexpf(1.0f, -e);
   }
+  SMPLR_TL_STAMP(1);
   const int nwin = (nslots + SB_SLOTS - 1) / SB_SLOTS;    // 1 in the standard pipeline
   for (int win = 0; win < nwin; ++win) {
     const int base = win * SB_SLOTS;
@@ -977,6 +1011,7 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     if (DET) for (int i = tid; i < nsl * 2; i += nthr) acc64[i] = 0ull;
     else for (int i = tid; i < nsl * 2; i += nthr) acc[i] = 0.0f;
     __syncthreads();
+    SMPLR_TL_STAMP(2);
     if (ro < W) {
       // (the compiler would otherwise start on the first batch - and wait for it - in front of the barrier)
 #pragma unroll
@@ -987,11 +1022,14 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
         seg_bwd_row<false, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
       else seg_bwd_row<true, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale, pa, pg);
     }
+    SMPLR_TL_STAMP(24);
     __syncthreads();
+    SMPLR_TL_STAMP(25);
     float *dst = part + (((size_t)n * gridDim.x + blockIdx.x) * SB_NWIN + win) * (SB_SLOTS * 2);
     if (DET) for (int i = tid; i < nsl * 2; i += nthr) dst[i] = (float)(long long)acc64[i] * inv_scale;
     else for (int i = tid; i < nsl * 2; i += nthr) dst[i] = acc[i];
   }
+  SMPLR_TL_STAMP(26);
 }
 
 __global__ __launch_bounds__(256) void seg_bwd_merge_kernel(const float *__restrict__ part,
@@ -1926,3 +1964,8 @@ int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg, co
 }
 
 }  // extern "C"
+
+#ifdef SMPLR_TL
+SMPLR_TL_EXPORT(bin, smplr::g_tl_bin, smplr::TL_BIN_WG * (smplr::BIN_T / 64) * 32)
+SMPLR_TL_EXPORT(segbwd, smplr::g_tl_segbwd, smplr::TL_SEGBWD_WG * 12 * 32)
+#endif

@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
 // needs <= 72 registers: 65 with T built row by row)
 // One block = 256 vertices x SKB_MB meshes (the 24 skinning weights of a vertex are loaded once and
 // kept in registers / LDS for all of them).  part layout per (mesh, block): 288 dA + 4 dcam floats.
+#ifdef SMPLR_TL
+constexpr int TL_SKIN_WG = 3456;
+__device__ unsigned g_tl_skin[TL_SKIN_WG * (SKB_T / 64) * 32];
+#endif
 constexpr int SKB_PART = 292;
 constexpr int SKB_MB = 1;
 
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
 
   static_assert(SKB_MB == 1, "one mesh per block");
   const int n = blockIdx.y;                   // block-uniform
+  SMPLR_TL_WAVE(g_tl_skin, SKB_T / 64, blockIdx.y * gridDim.x + blockIdx.x, TL_SKIN_WG)
   // Every global operand of the block is requested here, before the first barrier: the weights,
   // the mesh's joint matrix, the vertex and its incoming gradients (clamped, unconditional loads:
   // a per-lane condition around a load costs a branch and a drained vmcnt each), so the block
@@ -200,7 +205,9 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
     if (slot >= 0) { gp0 += sx; gp1 += sy; }
   }
   if (tid < 72) sAj[tid] = aj;
+  SMPLR_TL_STAMP(1);
   __syncthreads();
+  SMPLR_TL_STAMP(2);
 
   const int cr = li >> 2, cc = li & 3;   // dT component j = li = r*4+c  (valid for li < 12)
 
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
     // lane (li, lk) of step s holds w[vertex 64 wave + 4 s + lk][joint li] and [joint 16 + li]
     // (4 rows x 64-B segments per load); 32 loads per wave, requested once T is done (their latency
     // overlaps the barrier; asked for at the top they cost 32 live registers = one wave per SIMD).
+    SMPLR_TL_STAMP(3);
     float wa0[8], wa1[8];        // a ring of 8 steps: steps 8..15 are requested as the first eight are consumed
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
@@ -261,6 +269,7 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
     sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
     sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
     __syncthreads();
+    SMPLR_TL_STAMP(4);
 
     // dA tile on the matrix cores: D[joint][comp] += sum_k w[vk][joint] * g[vk][comp>>2]*ph[vk][comp&3]
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
         wa1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o1 + (s + 8) * 384, 0, 0));
       }
     }
+    SMPLR_TL_STAMP(5);
     // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
     if (li < 12) {
 #pragma unroll
@@ -291,12 +301,14 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
       sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
     }
     __syncthreads();
+    SMPLR_TL_STAMP(6);
     for (int e = tid; e < SKB_PART; e += SKB_T) {
       float acc = 0.f;
 #pragma unroll
       for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
       part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
     }
+    SMPLR_TL_STAMP(7);
   }
 }
 
@@ -459,3 +471,7 @@ int smplr_project_bwd(const float *dproj, const float *verts, const float *cam, 
 }
 
 }  // extern "C"
+
+#ifdef SMPLR_TL
+SMPLR_TL_EXPORT(skin, smplr::g_tl_skin, smplr::TL_SKIN_WG * (smplr::SKB_T / 64) * 32)
+#endif

@@ -1,14 +1,15 @@
-"""Reads the in-kernel clock stamps a timeline build of seg_bwd_kernel (raster.hip built with the SB_TL edits of
-DESIGN.md section 4, `lib_tl.so` copied over the library) leaves in its workspace: per wave, the shader clock at
-kernel entry, after the header load, after the zeroing barrier, around each batch of 8 pixels, at the closing barrier
-and at exit, plus HW_ID / XCC_ID.  Prints the median wave's phase lengths and how many workgroups shared a CU.  GPU only."""
+"""seg_bwd_kernel by phase, from the in-kernel clock stamps of a timeline build (bash tools/build_tl.sh; run as
+`bash tools/ab_run.sh "python tools/probes/segbwd_timeline.py" tl` on the GPU box): per wave the shader clock at entry,
+after the header load, after the zeroing barrier, around each batch of 8 pixels of the row walk, at the closing barrier
+and at exit.  B = 128, W = 48.  GPU only."""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timeline import placement, read_stamps  # noqa: E402
 import bench  # noqa: E402
 from ilps_amd import ops  # noqa: E402
 from ilps_amd.smpl_model import synthetic_smpl_model  # noqa: E402
@@ -28,32 +29,21 @@ def main():
     for it in range(3):
         ws, nsplit = ops._seg_bwd(dseg, arg, rec, consts.V, W, pt, merge=False)
     torch.cuda.synchronize()
-    t = ws.view(torch.int32).cpu().numpy().view(np.uint32)[:B * nsplit * 5 * 8192].reshape(B, nsplit, 5, 8192)[:, :, 4, :]
     nw = 12
-    st = t[:, :, :nw * 32].reshape(B, nsplit, nw, 32).astype(np.int64)
-    t0 = st[..., 0]
-    d = (st - t0[..., None]) & 0xFFFFFFFF
-    names = {1: "header", 2: "zeroed", 16: "row done", 17: "barrier", 18: "exit"}
-    for b in range(6):
+    t = read_stamps("segbwd", B * nsplit, nw)
+    d = (t - t[..., :1]) & 0xFFFFFFFF
+    names = {1: "header", 2: "zeroed", 24: "row done", 25: "barrier", 26: "exit"}
+    for b in range(W // 8):
         names[3 + 2 * b] = "batch %d gathered" % b
         names[4 + 2 * b] = "batch %d summed" % b
     print("median / p90 wave, clocks since the wave's entry:")
     for i in sorted(names):
         v = d[..., i].reshape(-1)
         print("  %-18s %8.0f %8.0f" % (names[i], np.median(v), np.percentile(v, 90)))
-    # spread of entry times over the launch, and co-residency
-    allt0 = t0.reshape(-1)
-    rd = d[..., 16]
-    print("row done, by wave of the workgroup (median): " + " ".join("%d" % np.median(rd[:, :, w]) for w in range(nw)))
-    print("row done: workgroup max, median over workgroups %d; slowest workgroup %d" % (np.median(rd.max(axis=2)), rd.max()))
-    hw = st[..., 20][:, :, 0]
-    xcc = st[..., 21][:, :, 0] & 0xF
-    cu = (hw >> 8) & 0xF
-    se = (hw >> 13) & 0x7
-    sh = (hw >> 12) & 1
-    key = (xcc * 8 + se) * 32 + sh * 16 + cu
-    uniq, cnt = np.unique(key.reshape(-1), return_counts=True)
-    print("workgroups %d on %d distinct (xcc, se, sh, cu); per CU: max %d" % (key.size, uniq.size, cnt.max()))
+    rd = d[..., 24]
+    print("row done, by wave of the workgroup (median): " + " ".join("%d" % np.median(rd[:, w]) for w in range(nw)))
+    print("row done: workgroup max, median over workgroups %d; slowest workgroup %d" % (np.median(rd.max(axis=1)), rd.max()))
+    placement(t)
 
 
 if __name__ == "__main__":
