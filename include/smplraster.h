@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMPLR_ABI_VERSION 4
+#define SMPLR_ABI_VERSION 5
 #define SMPLR_NJ 24            /* joints                                   */
 #define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
 #define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
@@ -206,6 +206,17 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
                       const int32_t *part_pos, const int32_t *part_off, int P, int K,
                       void *workspace, float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot,
                       void *stream);
+
+/* smplr_skin_fwd + smplr_vis_seg_fwd in ONE call of two launches (what the fused decoder runs for models whose
+ * skinning rows have <= 4 non-zeros and no vertex sampling, V <= 7168): the binning workgroup of a mesh skins and
+ * projects the mesh's vertices itself (batch_smpl.py:135-145 + projection.py:62-79, the arithmetic of smplr_skin_fwd
+ * bit for bit) and writes verts (B,V,3) and proj (B,V,3) out, then goes on as smplr_vis_seg_fwd.  cam = the rows of x
+ * (camera in columns 0..3), x_stride floats apart.  Same workspace and outputs as smplr_vis_seg_fwd.               */
+int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
+                           int x_stride, int B, int V, int W, int grid_wh, int ref_compat,
+                           const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,
+                           float *verts, float *proj, float *mask, float *seg, int16_t *arg, float *rec,
+                           int16_t *vslot, void *stream);
 
 /* The two stages of smplr_seg_fwd / smplr_vis_seg_fwd as separate entry points (one launch each; calling
  * them back to back IS the fused call, bit for bit) - for callers that re-rasterise a binned batch and for

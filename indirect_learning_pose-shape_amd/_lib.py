@@ -52,6 +52,7 @@ SIGNATURES = {
     "smplr_seg_slots": (c_int, [I, I]),
     "smplr_seg_fwd": (c_int, [P, P, I, I, I, P, P, I, I, P, P, P, P, P, P]),
     "smplr_vis_seg_fwd": (c_int, [P, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P, P]),
+    "smplr_skin_vis_seg_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P, P, P, P]),
     "smplr_seg_bin": (c_int, [P, P, I, I, I, I, I, P, P, I, I, P, P, P, P]),
     "smplr_seg_raster": (c_int, [I, I, I, I, P, P, P, P, P]),
     "smplr_seg_bwd_nsplit": (c_int, [I, I]),
@@ -89,7 +90,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.smplr_abi_version() != 4:
+    if lib.smplr_abi_version() != 5:
         raise RuntimeError("libsmplraster_hip.so ABI version mismatch")
     _lib = lib
     return lib

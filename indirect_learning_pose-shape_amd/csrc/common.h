@@ -108,6 +108,38 @@ int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
                              int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st);
 
+// Linear-blend skinning of one vertex from its <= 4 (weight, joint) pairs against the mesh's 24 x 12 joint matrix in
+// LDS (sAj: 72 float4), then the orthographic projection.  One definition for the two kernels that must
+// agree bit for bit: skin_fwd_kernel (skin.hip) and the binning kernel that skins its own vertices (raster.hip).
+__device__ __forceinline__ void skin_T_sparse(const float4 *sAj, const float4 ww, const float4 jj, float T[12]) {
+  const float w[4] = {ww.x, ww.y, ww.z, ww.w};
+  const int jx[4] = {(int)jj.x, (int)jj.y, (int)jj.z, (int)jj.w};
+#pragma unroll
+  for (int e = 0; e < 12; ++e) T[e] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 r0 = sAj[jx[k] * 3], r1 = sAj[jx[k] * 3 + 1], r2 = sAj[jx[k] * 3 + 2];
+    const float wj = w[k];
+    T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
+    T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
+    T[8] = fmaf(wj, r2.x, T[8]); T[9] = fmaf(wj, r2.y, T[9]); T[10] = fmaf(wj, r2.z, T[10]); T[11] = fmaf(wj, r2.w, T[11]);
+  }
+}
+// (Plain expressions on purpose: hipcc contracts them the same way in both kernels - checked in the ISA, and
+// test_skinning_inside_the_binning_kernel_equals_separate_calls compares the outputs bit for bit at five sizes - and
+// the way it did before the function was shared, so the projected positions, and with them every near-tie of the
+// rasterisers against the float64 oracle, are the ones the parity tests were tuned on.)
+__device__ __forceinline__ void skin_apply(const float T[12], float p0, float p1, float p2, float &X, float &Y, float &Z) {
+  X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
+  Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
+  Z = T[8] * p0 + T[9] * p1 + T[10] * p2 + T[11];
+}
+// (u, v) = cam[2:4] + (X, Y) * cam[0:2]  (projection.py:62-79)
+__device__ __forceinline__ float project_u(float X, float c0, float c2) { return c2 + X * c0; }
+
+// What the binning kernel needs to skin its own vertices (smplr_skin_vis_seg_fwd); all NULL otherwise.
+struct SkinIn { const float *v_posed, *top4, *A, *cam; int x_stride; float *verts, *proj; };
+
 // Depth as an unsigned key whose order is the float order (visibility z-buffer, compute_mask.py:98-103).
 __device__ __forceinline__ unsigned int orderable(float z) {
   z += 0.0f;  // -0 -> +0 so that equal depths compare equal (tf.argmax treats them as ties)

@@ -46,6 +46,8 @@ constexpr int BIN_T = 1024;
 constexpr int TL_BIN_WG = 128, TL_SEGBWD_WG = 256;
 __device__ unsigned g_tl_bin[TL_BIN_WG * (BIN_T / 64) * 32];
 __device__ unsigned g_tl_segbwd[TL_SEGBWD_WG * 12 * 32];
+constexpr int TL_RASTER_WG = 1152;
+__device__ unsigned g_tl_raster[TL_RASTER_WG * 16 * 32];
 #endif
 constexpr int IPT_MAX = 8;           // part-table slots per bin thread: K <= 8192
 
@@ -112,7 +114,10 @@ __device__ __forceinline__ Slot classify(float u, float v, float m, int pos, int
 // STAGE = true keeps every vertex' (u, v) in LDS as well (2 VP floats): the workgroup then makes
 // ONE round trip to global memory - its vertices (coalesced) and its part-table slots, requested
 // together at the top - and the per-slot gathers of classification become LDS reads.
-template <bool VIS, bool STAGE>
+// SKIN = true (with VIS and STAGE): the workgroup skins and projects its mesh's vertices itself (skin_fwd_kernel's
+// arithmetic, common.h) from v_posed, the sparse weights and the joint matrices, writes verts and proj out and goes on
+// with the values in registers: the skinning launch, its ramp and the re-read of proj go away.
+template <bool VIS, bool STAGE, bool SKIN>
 __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict__ proj,
                                                         float *__restrict__ mask,
                                                         const int *__restrict__ part_pos,
@@ -120,11 +125,13 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
                                                         int VP, int W, int S, float4 *__restrict__ G,
                                                         int *__restrict__ goff, int *__restrict__ lstart,
                                                         uint2 *__restrict__ lrec, int vgrid, int ref_compat,
-                                                        short *__restrict__ vslot) {
+                                                        short *__restrict__ vslot, SkinIn sk) {
   // (16-B aligned: the 64-bit z-buffer keys behind the counters need 8, whatever the static LDS in front)
   extern __shared__ __attribute__((aligned(16))) int s_cnt[];   // npix | VIS: z-buffer keys, visible flags | STAGE: u[VP], v[VP]
   __shared__ int s_poff[33], s_gstart[33], s_gpad[33], s_wave[BIN_T / 64], s_gb[BIN_T];
   __shared__ int s_any_empty, s_nonunit;
+  __shared__ float4 sAj[SKIN ? 72 : 1];
+  static_assert(!SKIN || (VIS && STAGE), "the skinning form is built for the decoder's path only");
   const int n = blockIdx.x, tid = threadIdx.x;
   SMPLR_TL_WAVE(g_tl_bin, BIN_T / 64, n, TL_BIN_WG)
   const int npix = W * W;
@@ -141,11 +148,30 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
   const int k0 = tid * ipt, k1 = min(K, k0 + ipt);
   int pos[IPT_MAX];
+  if (!SKIN) {                                  // (the skinning form asks after its vertices are done: registers)
 #pragma unroll
-  for (int j = 0; j < IPT_MAX; ++j) pos[j] = (j < ipt) ? part_pos[min(k0 + j, K - 1)] : 0;
-  constexpr int VPT = 8;                        // vertices per thread and trip: 8192 per trip
+    for (int j = 0; j < IPT_MAX; ++j) pos[j] = (j < ipt) ? part_pos[min(k0 + j, K - 1)] : 0;
+  }
+  constexpr int VPT = SKIN ? 7 : 8;             // vertices per thread and trip: 8192 per trip (skinning: 7168, one trip)
   float vu[VPT], vv[VPT], vz[VPT];
-  if (VIS || STAGE) {
+  float4 tw[SKIN ? VPT : 1], tj[SKIN ? VPT : 1], aj = {0.f, 0.f, 0.f, 0.f};
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+  if (SKIN) {                                   // (VP <= 7 BIN_T: one trip, checked by the launcher)
+    aj = reinterpret_cast<const float4 *>(sk.A + (size_t)n * 288)[tid < 72 ? tid : 71];
+    const float *c = sk.cam + (size_t)n * sk.x_stride;
+    c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
+    const float *vp = sk.v_posed + (size_t)n * VP * 3;
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = min(tid + q * BIN_T, VP - 1);
+      const float4 *tp = reinterpret_cast<const float4 *>(sk.top4 + (size_t)v * 8);
+      tw[q] = tp[0];
+      tj[q] = tp[1];
+      vu[q] = vp[v * 3 + 0];                    // the posed vertex for now
+      vv[q] = vp[v * 3 + 1];
+      vz[q] = vp[v * 3 + 2];
+    }
+  } else if (VIS || STAGE) {
 #pragma unroll
     for (int q = 0; q < VPT; ++q) {
       const int v = min(tid + q * BIN_T, VP - 1);
@@ -163,9 +189,30 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
     for (int i = tid; i < words; i += BIN_T) vis[i] = 0u;
   }
+  if (SKIN && tid < 72) sAj[tid] = aj;
   SMPLR_TL_STAMP(1);
   __syncthreads();
   SMPLR_TL_STAMP(2);
+  if (SKIN) {
+    float *vo = sk.verts + (size_t)n * VP * 3, *po = sk.proj + (size_t)n * VP * 3;
+#pragma unroll
+    for (int q = 0; q < VPT; ++q) {
+      const int v = tid + q * BIN_T;
+      float T[12], X, Y, Z;
+      skin_T_sparse(sAj, tw[q], tj[q], T);
+      skin_apply(T, vu[q], vv[q], vz[q], X, Y, Z);
+      vu[q] = project_u(X, c0, c2);
+      vv[q] = project_u(Y, c1, c3);
+      vz[q] = Z;
+      if (v < VP) {
+        vo[v * 3 + 0] = X; vo[v * 3 + 1] = Y; vo[v * 3 + 2] = Z;
+        po[v * 3 + 0] = vu[q]; po[v * 3 + 1] = vv[q]; po[v * 3 + 2] = Z;
+      }
+      __builtin_amdgcn_sched_barrier(0);          // one vertex at a time: seven T matrices at once do not fit the registers
+    }
+#pragma unroll
+    for (int j = 0; j < IPT_MAX; ++j) pos[j] = (j < ipt) ? part_pos[min(k0 + j, K - 1)] : 0;
+  }
   if (VIS || STAGE) {
     const float fG = (float)vgrid;
     for (int base = 0; base < VP; base += VPT * BIN_T) {
@@ -574,6 +621,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   const int n = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
   if (n >= B) return;                                    // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
+  SMPLR_TL_WAVE(g_tl_raster, 16, n * ntiles + tile, TL_RASTER_WG)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
   const int g = wave / WPT, pw = wave % WPT;             // part range, pixel sub-tile
   const int pt = pw * 64 + lane;                         // pixel within the tile
@@ -634,7 +682,9 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
 #else
   const bool tbl = in_lds && nrows * RS <= ARENA - toff;  // block-uniform
 #endif
+  SMPLR_TL_STAMP(1);
   __syncthreads();
+  SMPLR_TL_STAMP(2);
   if (tbl) {
     // thread -> (group of 4 records k4 = tid % 256, rows tid / 256, + 4, ...): lbase <= NREC = 1 024 records
     const int n4 = (lbase + 3) >> 2, k4 = tid & 255;
@@ -648,6 +698,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     }
     __syncthreads();
   }
+  SMPLR_TL_STAMP(3);
   const unsigned rowoff = (unsigned)(toff + (r - row0) * RS) * 4u;
   // the first 8 local records of each of this lane's merge pixels are fetched now and used after the pair loop
   uint2 lr0[NIT];
@@ -669,6 +720,9 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     ps = (g == 0) ? 0 : __popcll(b0);
     pe = (g == NG - 1) ? P : __popcll(b1);
   }
+#ifdef SMPLR_TL
+  const int ps0 = ps, pe0 = pe;
+#endif
 
   {
     // the part offsets sit in a VGPR, one per lane (P + 1 <= 32), and a part's range is a v_readlane away
@@ -725,7 +779,9 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       beg = end;
     }
   }
+  SMPLR_TL_STAMP(4);
   __syncthreads();
+  SMPLR_TL_STAMP(5);
   // The tile now holds every part's best visible vertex.  All 16 waves merge the local records (invisible
   // vertices that round to the pixel) and write the tile out: 8 lanes per pixel, each taking every 8th record
   // of the pixel's list, then 4 channels of its row (coalesced 128-B / 64-B pixel rows).  A record replaces the
@@ -796,6 +852,10 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       *reinterpret_cast<short4 *>(arg + (size_t)n * npix * 32 + (po * 32u + (unsigned)c4)) = o4;
     }
   }
+  SMPLR_TL_STAMP(6);
+#ifdef SMPLR_TL
+  if (tl__) { tl__[7] = (unsigned)(pe0 - ps0); tl__[8] = (unsigned)g; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1749,12 +1809,17 @@ namespace smplr {
 // stage 1: binning (optionally with compute_mask fused in front) -> rec, workspace (part offsets, pixel lists), vslot
 static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fuse_vis, int grid_wh, int ref_compat,
                         int B, int VP, int W, const int32_t *part_pos, const int32_t *part_off, int P, int K,
-                        void *workspace, float *rec, int16_t *vslot, void *stream) {
+                        void *workspace, float *rec, int16_t *vslot, void *stream, SkinIn sk = SkinIn{}) {
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
                 "%s: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, VP, W, P, K);
   SMPLR_REQUIRE(!fuse_vis || (grid_wh > 0 && grid_wh <= 128), "%s: bad grid_wh=%d (max 128)", fn, grid_wh);
   if (B == 0) return 0;
   SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && rec, "%s: null pointer", fn);
+  const bool skin = sk.v_posed != nullptr;
+  SMPLR_REQUIRE(!skin || (sk.top4 && sk.A && sk.cam && sk.x_stride >= 4 && sk.verts && sk.proj == proj && fuse_vis &&
+                          VP <= 7 * BIN_T),
+                "%s: the skinning form needs the sparse weights, A, camera rows, verts, proj, the fused mask and V <= %d",
+                fn, 7 * BIN_T);
   hipStream_t st = as_stream(stream);
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
@@ -1772,18 +1837,20 @@ static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fus
   const bool stage = lds + slot_lds + (size_t)VP * 8 <= 150 * 1024;
   if (stage) lds += (size_t)VP * 8;
   lds += slot_lds;
-#define SMPLR_BIN_LAUNCH(VIS_, STAGE_)                                                                        \
+#define SMPLR_BIN_LAUNCH(VIS_, STAGE_, SKIN_)                                                                 \
   {                                                                                                           \
-    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<VIS_, STAGE_>), lds);                 \
+    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<VIS_, STAGE_, SKIN_>), lds);          \
     if (rc) return rc;                                                                                        \
-    hipLaunchKernelGGL((seg_bin_kernel<VIS_, STAGE_>), dim3(B), dim3(BIN_T), lds, st, proj, mask, part_pos,   \
-                       part_off, P, K, VP, W, S, G, goff, lstart, lrec, fuse_vis ? grid_wh : 1, ref_compat,   \
-                       reinterpret_cast<short *>(vslot));                                                     \
+    hipLaunchKernelGGL((seg_bin_kernel<VIS_, STAGE_, SKIN_>), dim3(B), dim3(BIN_T), lds, st, proj, mask,      \
+                       part_pos, part_off, P, K, VP, W, S, G, goff, lstart, lrec, fuse_vis ? grid_wh : 1,     \
+                       ref_compat, reinterpret_cast<short *>(vslot), sk);                                     \
   }
-  if (fuse_vis && stage) SMPLR_BIN_LAUNCH(true, true)
-  else if (fuse_vis) SMPLR_BIN_LAUNCH(true, false)
-  else if (stage) SMPLR_BIN_LAUNCH(false, true)
-  else SMPLR_BIN_LAUNCH(false, false)
+  SMPLR_REQUIRE(!skin || stage, "%s: the skinning form needs the staged (u, v) to fit LDS", fn);
+  if (skin) SMPLR_BIN_LAUNCH(true, true, true)
+  else if (fuse_vis && stage) SMPLR_BIN_LAUNCH(true, true, false)
+  else if (fuse_vis) SMPLR_BIN_LAUNCH(true, false, false)
+  else if (stage) SMPLR_BIN_LAUNCH(false, true, false)
+  else SMPLR_BIN_LAUNCH(false, false, false)
 #undef SMPLR_BIN_LAUNCH
   SMPLR_LAUNCH_CHECK(fn);
   return 0;
@@ -1845,6 +1912,19 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
                       float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
   return smplr::seg_fwd_impl("smplr_vis_seg_fwd", proj, mask, true, grid_wh, ref_compat, B, VP, W, part_pos,
                              part_off, P, K, workspace, seg, arg, rec, vslot, stream);
+}
+
+int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam, int x_stride,
+                           int B, int V, int W, int grid_wh, int ref_compat, const int32_t *part_pos,
+                           const int32_t *part_off, int P, int K, void *workspace, float *verts, float *proj,
+                           float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B <= 0 || (v_posed && lbs_top4 && A && cam && verts && proj), "smplr_skin_vis_seg_fwd: null pointer");
+  const SkinIn sk{v_posed, lbs_top4, A, cam, x_stride, verts, proj};
+  int rc = seg_bin_impl("smplr_skin_vis_seg_fwd", proj, mask, true, grid_wh, ref_compat, B, V, W, part_pos, part_off, P,
+                        K, workspace, rec, vslot, stream, sk);
+  if (rc) return rc;
+  return seg_raster_impl("smplr_skin_vis_seg_fwd", B, W, P, K, workspace, rec, seg, arg, stream);
 }
 
 int smplr_seg_bwd_nsplit(int B, int W) {
@@ -1968,4 +2048,5 @@ int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg, co
 #ifdef SMPLR_TL
 SMPLR_TL_EXPORT(bin, smplr::g_tl_bin, smplr::TL_BIN_WG * (smplr::BIN_T / 64) * 32)
 SMPLR_TL_EXPORT(segbwd, smplr::g_tl_segbwd, smplr::TL_SEGBWD_WG * 12 * 32)
+SMPLR_TL_EXPORT(raster, smplr::g_tl_raster, smplr::TL_RASTER_WG * 16 * 32)
 #endif

@@ -38,13 +38,12 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
   const int v = blockIdx.x * 256 + threadIdx.x;
   const bool live = v < V;
   const int vc = live ? v : V - 1;
-  float w[SPARSE ? 4 : 24];
-  int jx[4] = {0, 0, 0, 0};
+  float w[SPARSE ? 1 : 24];
+  float4 ww = {0.f, 0.f, 0.f, 0.f}, jj = {0.f, 0.f, 0.f, 0.f};
   if (SPARSE) {
     const float4 *tp = reinterpret_cast<const float4 *>(top4 + (size_t)vc * 8);
-    const float4 ww = tp[0], jj = tp[1];
-    w[0] = ww.x; w[1] = ww.y; w[2] = ww.z; w[3] = ww.w;
-    jx[0] = (int)jj.x; jx[1] = (int)jj.y; jx[2] = (int)jj.z; jx[3] = (int)jj.w;
+    ww = tp[0];
+    jj = tp[1];
   } else {
     const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
 #pragma unroll
@@ -73,23 +72,15 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
     if (SPARSE) {
       if (threadIdx.x < 72) sAj[threadIdx.x] = reinterpret_cast<const float4 *>(An)[threadIdx.x];
       __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 r0 = sAj[jx[k] * 3], r1 = sAj[jx[k] * 3 + 1], r2 = sAj[jx[k] * 3 + 2];
-        const float wj = w[k];
-        T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
-        T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);
-        T[8] = fmaf(wj, r2.x, T[8]); T[9] = fmaf(wj, r2.y, T[9]); T[10] = fmaf(wj, r2.z, T[10]); T[11] = fmaf(wj, r2.w, T[11]);
-      }
+      skin_T_sparse(sAj, ww, jj, T);
     } else {
 #pragma unroll
       for (int j = 0; j < 24; ++j)
 #pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = fmaf(w[j], An[j * 12 + e], T[e]);
+        for (int e = 0; e < 12; ++e) T[e] = fmaf(w[SPARSE ? 0 : j], An[j * 12 + e], T[e]);
     }
-    const float X = T[0] * p0 + T[1] * p1 + T[2] * p2 + T[3];
-    const float Y = T[4] * p0 + T[5] * p1 + T[6] * p2 + T[7];
-    const float Z = T[8] * p0 + T[9] * p1 + T[10] * p2 + T[11];
+    float X, Y, Z;
+    skin_apply(T, p0, p1, p2, X, Y, Z);
     if (live) {
       if (verts) {
         float *o = verts + ((size_t)n * V + v) * 3;
@@ -97,8 +88,8 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
       }
       if (proj && sampled) {
         float *o = proj + ((size_t)n * VP + vp_idx) * 3;
-        o[0] = c2 + X * c0;
-        o[1] = c3 + Y * c1;
+        o[0] = project_u(X, c0, c2);
+        o[1] = project_u(Y, c1, c3);
         o[2] = Z;
       }
     }

@@ -14,6 +14,7 @@ Reference callables replaced (reference file:line):
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -322,6 +323,32 @@ def _vis_seg_fwd(proj, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None, 
                                 ptr(pt.part_off), pt.P, pt.K, ptr(ws), ptr(mask), ptr(seg), ptr(arg), ptr(rec),
                                 ptr(vslot), stream()), "smplr_vis_seg_fwd")
     return mask, seg, arg, rec
+
+
+@on_device
+def _skin_vis_seg_fwd(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, grid_wh=64, ref_compat=True, out=None,
+                      vslot=None):
+    """_skin_fwd + _vis_seg_fwd as one call of two launches (smplr_skin_vis_seg_fwd): the binning workgroups skin
+    their own vertices.  Needs the sparse skinning weights and no vertex sampling.
+    -> verts, proj, mask, seg, arg, rec (bit for bit what the two calls give)."""
+    lib = _lib.load()
+    B, V = v_posed.shape[0], c.V
+    if c.lbs_top4 is None or pt.VP != V:
+        raise RuntimeError("_skin_vis_seg_fwd needs <= 4 skinning weights per vertex and vertex_sampling = 1")
+    ws = _workspace(lib.smplr_seg_workspace(B, V, W, pt.P, pt.K), v_posed)
+    if out is not None:
+        verts, proj, mask, seg, arg, rec = out
+    else:
+        verts, proj = _empty((B, V, 3), v_posed), _empty((B, V, 3), v_posed)
+        mask = _empty((B, V), v_posed)
+        seg = _empty((B, W, W, pt.P + 1), v_posed)
+        arg = _empty((B, W, W, 32), v_posed, torch.int16)
+        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), v_posed)
+    check(lib.smplr_skin_vis_seg_fwd(ptr(v_posed), ptr(c.lbs_top4), ptr(A), ptr(cam), cam.shape[1], B, V, W,
+                                     int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
+                                     pt.K, ptr(ws), ptr(verts), ptr(proj), ptr(mask), ptr(seg), ptr(arg), ptr(rec),
+                                     ptr(vslot), stream()), "smplr_skin_vis_seg_fwd")
+    return verts, proj, mask, seg, arg, rec
 
 
 @on_device
@@ -806,6 +833,11 @@ class DecoderFn(torch.autograd.Function):
         else:
             silh = sarg = torch.empty(0, device=x.device)
 
+        # the binning workgroups skin their own vertices (one launch less) when the skinning rows are sparse, every
+        # vertex is rasterised and a mesh fits one trip of the binning kernel; SMPLR_FUSE_SKIN=0 keeps the two calls
+        fuse_skin = (consts.lbs_top4 is not None and vs == 1 and V <= 7168 and 0 < grid_wh <= 128
+                     and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
+
         def run(lo, hi):
             xs = x[lo:hi]
             if consts.blend3_fwd is not None:
@@ -813,10 +845,15 @@ class DecoderFn(torch.autograd.Function):
             else:
                 coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
                 _blend_fwd(coef, consts, hi - lo, out=v_posed[lo:hi])
-            _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
-                      out=(verts[lo:hi], proj[lo:hi]))
-            _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,
-                         out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
+            if fuse_skin:
+                _skin_vis_seg_fwd(v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, grid_wh, ref_compat,
+                                  out=(verts[lo:hi], proj[lo:hi], mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]),
+                                  vslot=vslot[lo:hi])
+            else:
+                _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
+                          out=(verts[lo:hi], proj[lo:hi]))
+                _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,
+                             out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
             if with_silh:
                 _silh_fwd(proj[lo:hi], Ws, out=(silh[lo:hi], sarg[lo:hi]))
 

@@ -37,7 +37,7 @@ def test_ctypes_table_matches_header():
     from ilps_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     lib = _lib.load()
-    assert lib.smplr_abi_version() == 4
+    assert lib.smplr_abi_version() == 5
     # argument errors are reported without touching the GPU
     rc = lib.smplr_visibility(None, 1, 6890, 0, 1, None, None)
     assert rc == -1 and b"grid_wh" in lib.smplr_last_error()

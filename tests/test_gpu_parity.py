@@ -483,6 +483,37 @@ def test_blend3_wide_dynamic_range():
     assert np.all(got[:, 217:] == 0)
 
 
+@pytest.mark.parametrize("B,W", [(1, 48), (5, 48), (33, 32), (128, 48), (3, 96)])
+def test_skinning_inside_the_binning_kernel_equals_separate_calls(smpl_model, B, W):
+    """smplr_skin_vis_seg_fwd (the binning workgroup skins its own vertices) == smplr_skin_fwd + smplr_vis_seg_fwd,
+    bit for bit: verts, proj, mask, scores, winners."""
+    from ilps_amd import ops
+    d = dev()
+    c = ops.SMPLConstants.from_model(smpl_model, d)
+    pt = ops.get_part_table(1, d, c.V)
+    x = t(make_x(B, W, seed=300 + B))
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
+    vp = ops._blend_fwd(coef, c, B)
+    v1, p1 = ops._skin_fwd(vp, A, c, cam=x)
+    vs1 = torch.empty(B, c.V, dtype=torch.int16, device=d)
+    m1, s1, a1, r1 = ops._vis_seg_fwd(p1, W, pt, vslot=vs1)
+    vs2 = torch.empty(B, c.V, dtype=torch.int16, device=d)
+    v2, p2, m2, s2, a2, r2 = ops._skin_vis_seg_fwd(vp, A, c, x, W, pt, vslot=vs2)
+    assert torch.equal(v1, v2) and torch.equal(p1, p2) and torch.equal(m1, m2)
+    assert torch.equal(s1, s2)
+    assert torch.equal(a1[..., 0], a2[..., 0])                      # clip gates
+    # (slot ids of local records depend on LDS-atomic arrival order: compare the winning vertices)
+    assert torch.equal(ops.argmin_vertices(a1, r1), ops.argmin_vertices(a2, r2))
+    # the vertex -> slot maps are inverse to their own records
+    for vs_, r_ in ((vs1, r1), (vs2, r2)):
+        pos = r_[..., 3].contiguous().view(torch.int32).to(torch.int64)
+        sl = vs_.to(torch.int64)
+        ok = sl >= 0
+        got = torch.gather(pos, 1, sl.clamp(min=0))
+        want = torch.arange(c.V, device=d).expand(B, -1)
+        assert torch.equal(got[ok], want[ok])
+
+
 def test_sparse_and_dense_skinning_bit_identical(smpl_model):
     """The <=4-influence fast path must equal the dense 24-joint path bit for bit, forward and backward."""
     import dataclasses

@@ -1,0 +1,47 @@
+"""raster_fwd_kernel by phase and by wave, from the in-kernel clock stamps of a timeline build (bash tools/build_tl.sh;
+`bash tools/ab_run.sh "python tools/probes/raster_timeline.py" tl` on the GPU box).  B = 128, W = 48.  GPU only."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _timeline import placement, read_stamps  # noqa: E402
+import bench  # noqa: E402
+from ilps_amd.decoder import SMPLDecoder  # noqa: E402
+
+NAMES = ["entry", "requests issued", "barrier (records in LDS)", "row tables built", "parts scanned", "barrier",
+         "merged + written"]
+
+
+def main():
+    B, W = 128, 48
+    dev = torch.device("cuda", 0)
+    dec = SMPLDecoder(None, img_wh=W)
+    x = torch.tensor(bench.make_x(B, W, 11), device=dev)
+    for it in range(3):
+        dec(x)
+    torch.cuda.synchronize()
+    t = read_stamps("raster", 1152, 16)
+    d = (t - t[..., :1]) & 0xFFFFFFFF
+    print("median / p90 / max over waves, clocks since the wave's entry:")
+    for i in range(1, 7):
+        v = d[..., i].reshape(-1)
+        print("  %-26s %8.0f %8.0f %8.0f" % (NAMES[i], np.median(v), np.percentile(v, 90), v.max()))
+    scan = d[..., 4] - d[..., 3]                       # (wg, wave)
+    print("part scan per wave: median %d, p10 %d, p90 %d; per workgroup max / mean of its 16 waves: median %.2f, p90 %.2f"
+          % (np.median(scan), np.percentile(scan, 10), np.percentile(scan, 90),
+             np.median(scan.max(1) / scan.mean(1)), np.percentile(scan.max(1) / scan.mean(1), 90)))
+    g = t[..., 8]
+    for k in range(4):
+        sel = scan[g == k]
+        print("  range %d: waves %d, scan median %d p90 %d, parts median %d" % (k, sel.size, np.median(sel), np.percentile(sel, 90),
+                                                                              np.median(t[..., 7][g == k])))
+    wait = d[..., 5] - d[..., 4]
+    print("wait at the barrier after the scan: median %d, p90 %d" % (np.median(wait), np.percentile(wait, 90)))
+    placement(t)
+
+
+if __name__ == "__main__":
+    main()
