@@ -540,14 +540,14 @@ def main():
             if os.path.exists(tfile) and B == 128 and W == 48:
                 try:
                     ks = json.load(open(tfile))["kernels"]
-                    tot = sum(v.get("hbm_bytes_per_launch", 0) for k, v in ks.items()
-                              if "pack" not in k and "copy" not in k)
+                    step_ks = [k for k in ks if "pack" not in k and "copy" not in k]
+                    tot = sum(ks[k].get("hbm_bytes_per_launch", 0) for k in step_ks)
                     gbs = tot / (ms * 1e-3) / 1e9
                     line["step_hbm"] = {"bound": "hbm", "traffic": int(tot), "achieved": round(gbs, 1),
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                        "note": "PMC FETCH_SIZE/WRITE_SIZE bytes of the step's 9 kernels (profiles/"
+                                        "note": "PMC FETCH_SIZE/WRITE_SIZE bytes of the step's %d kernels (profiles/"
                                                 "pmc_traffic.json) / graph step time: a chain of launch- and "
-                                                "latency-bound kernels at B = 128, not a bandwidth-bound stream"}
+                                                "latency-bound kernels at B = 128, not a bandwidth-bound stream" % len(step_ks)}
                 except Exception:
                     pass
             line["roofline"] = raster_roofline(x, consts, pt, W, stages)
