@@ -859,7 +859,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Segmentation backward.  grid (ceil(W/8), B), 256 threads = 8 strips x 32 channels: a 32-lane
+// Segmentation backward.  grid (ceil(W/rows), B), rows = 8 or 24 strips x 32 channels (block b of a mesh takes rows
+// b, b + nblocks, ...): a 32-lane
 // group walks one output row at a time, lane = channel, so dseg/arg are read as whole 128-B /
 // 64-B pixel rows (coalesced) and neighbouring lanes hit different parts.  Along a row the
 // arg-min of a part changes rarely, so each lane sums the run of pixels that share a slot in
