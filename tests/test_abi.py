@@ -42,6 +42,12 @@ def test_ctypes_table_matches_header():
     rc = lib.smplr_visibility(None, 1, 6890, 0, 1, None, None)
     assert rc == -1 and b"grid_wh" in lib.smplr_last_error()
     assert lib.smplr_blend_bwd_workspace(128, 20670) > 0
+    # the skinning + binning call refuses null operands, and an empty batch is a no-op
+    rc = lib.smplr_skin_vis_seg_fwd(None, None, None, None, 86, 1, 6890, 48, 64, 1, None, None, 31, 6879, None, None, None,
+                                    None, None, None, None, None, None)
+    assert rc == -1 and b"smplr_skin_vis_seg_fwd" in lib.smplr_last_error()
+    assert lib.smplr_skin_vis_seg_fwd(None, None, None, None, 86, 0, 6890, 48, 64, 1, None, None, 31, 6879, None, None,
+                                      None, None, None, None, None, None, None) == 0
     assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 27 * 292 * 4
 
 
