@@ -572,17 +572,18 @@ __device__ __forceinline__ void scan_parts_tbl(const char *base, int offv, int p
     float best = INFINITY;
     int bslot = -1;
     if (beg < end) {
-      unsigned bav = 0xffffffffu;
+      unsigned bav = (unsigned)beg * 4u;           // (no group lowers an infinite best: the first one is looked at)
       lds_scan_tbl<UNIT>(base, beg, end, rowoff, fc2, best, bav);
       // the winning group is looked at once more for the first record that attains the minimum
-      const unsigned wav = (bav == 0xffffffffu) ? (unsigned)beg * 4u : tbl_group(bav, rowoff);
+      const unsigned wav = tbl_group(bav, rowoff);
       f32x2 k01, k23;
       tbl_keys<UNIT>(base, wav, rowoff + wav, fc2, k01, k23);
       const int w23 = (k23.x == best) ? 2 : 3, w13 = (k01.y == best) ? 1 : w23;
       const int w = (int)(wav >> 2) + ((k01.x == best) ? 0 : w13);
       bslot = (best < INFINITY) ? w : -1;
     }
-    myS[p] = (best < INFINITY) ? fast_exp_neg(fast_sqrt(best)) : 0.0f;
+    // (no test for an empty part: sqrt(inf) = inf and v_exp_f32(-inf) = +0 exactly)
+    myS[p] = fast_exp_neg(fast_sqrt(best));
     myA[p] = (short)bslot;
     beg = end;
   }
