@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMPLR_ABI_VERSION 5
+#define SMPLR_ABI_VERSION 6
 #define SMPLR_NJ 24            /* joints                                   */
 #define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
 #define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
@@ -40,6 +40,10 @@ extern "C" {
 
 int smplr_abi_version(void);
 const char *smplr_last_error(void);
+/* sha256 (64 hex digits) over the sources this library was built from - csrc/*.hip, csrc/*.h (sorted by name) and
+ * this header, concatenated; the host side recomputes it from the files beside the library and refuses a stale
+ * library (`_lib.load`).  No reference counterpart: the reference ships no compiled code.                      */
+const char *smplr_build_id(void);
 
 /* ---- SMPLLayer.call: keras_smpl/batch_smpl.py:96-153 --------------------------------- */
 
@@ -101,7 +105,7 @@ size_t smplr_blend3_bwd_bytes(int N3);
 int smplr_blend3_pack(const float *blend, int N3, void *pk_fwd, void *pk_bwd, void *stream);
 int smplr_blend3_fwd(const void *coef3, const void *pk_fwd, const float *v_template,
                      int B, int N3, float *v_posed, void *stream);
-/* smplr_pose_fwd + smplr_blend3_fwd in ONE launch (what the decoder runs): the first ceil(B/4) workgroups are the
+/* smplr_pose_fwd + smplr_blend3_fwd in ONE launch (what the decoder runs): the first ceil(B/8) workgroups are the
  * pose kernel (Rs, J, A, J_transformed as smplr_pose_fwd writes them), every GEMM wave computes the coefficient rows
  * of its own 32 meshes itself instead of reading coef3 - same Rodrigues, same three-way split, so v_posed is what
  * the two separate calls give, bit for bit - and nothing is handed between workgroups.  The pose chain's latency
@@ -211,7 +215,13 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
  * skinning rows have <= 4 non-zeros and no vertex sampling, V <= 7168): the binning workgroup of a mesh skins and
  * projects the mesh's vertices itself (batch_smpl.py:135-145 + projection.py:62-79, the arithmetic of smplr_skin_fwd
  * bit for bit) and writes verts (B,V,3) and proj (B,V,3) out, then goes on as smplr_vis_seg_fwd.  cam = the rows of x
- * (camera in columns 0..3), x_stride floats apart.  Same workspace and outputs as smplr_vis_seg_fwd.               */
+ * (camera in columns 0..3), x_stride floats apart.  Same workspace and outputs as smplr_vis_seg_fwd.  verts, proj
+ * and mask may each be NULL: the backward of the decoder needs none of them (the record list carries the projected
+ * positions it uses), so a caller that only consumes seg saves their 82.7 + 82.7 + 27.6 KB per mesh of stores.
+ * smplr_skin_vis_seg_fits(V, W, grid_wh) = 1 when the form applies (the mesh's staged (u, v), its z-buffer, the
+ * pixel counters and the slot map fit the workgroup's LDS: W <= ~100 at V = 6890, grid_wh = 64); otherwise call
+ * smplr_skin_fwd and smplr_vis_seg_fwd.                                                                            */
+int smplr_skin_vis_seg_fits(int V, int W, int grid_wh);
 int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
                            int x_stride, int B, int V, int W, int grid_wh, int ref_compat,
                            const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,

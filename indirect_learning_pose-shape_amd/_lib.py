@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsmplraster_hip.so")
 
 KPAD = 220
 CHUNK = 8
+ABI_VERSION = 6          # SMPLR_ABI_VERSION of include/smplraster.h
 
 P = c_void_p
 I = c_int
@@ -25,6 +26,7 @@ I = c_int
 SIGNATURES = {
     "smplr_abi_version": (c_int, []),
     "smplr_last_error": (c_char_p, []),
+    "smplr_build_id": (c_char_p, []),
     "smplr_coef_ld": (c_int, [I]),
     "smplr_coef3_bytes": (c_size_t, [I]),
     "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P]),
@@ -52,6 +54,7 @@ SIGNATURES = {
     "smplr_seg_slots": (c_int, [I, I]),
     "smplr_seg_fwd": (c_int, [P, P, I, I, I, P, P, I, I, P, P, P, P, P, P]),
     "smplr_vis_seg_fwd": (c_int, [P, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P, P]),
+    "smplr_skin_vis_seg_fits": (c_int, [I, I, I]),
     "smplr_skin_vis_seg_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P, P, P, P]),
     "smplr_seg_bin": (c_int, [P, P, I, I, I, I, I, P, P, I, I, P, P, P, P]),
     "smplr_seg_raster": (c_int, [I, I, I, I, P, P, P, P, P]),
@@ -76,6 +79,29 @@ SIGNATURES = {
 _lib = None
 
 
+def source_build_id():
+    """sha256 over csrc/*.hip, csrc/*.h (sorted by name) and include/smplraster.h, concatenated: what
+    csrc/Makefile compiles into the library as smplr_build_id().  None when the sources are not beside the
+    library (an installed copy without csrc/)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    header = os.path.join(os.path.dirname(_HERE), "include", "smplraster.h")
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")))
+    if not names or not os.path.exists(header):
+        return None
+    h = hashlib.sha256()
+    for f in [os.path.join(csrc, n) for n in names] + [header]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_id():
+    """The id compiled into the loaded library."""
+    return load().smplr_build_id().decode("ascii")
+
+
 def load():
     """Load the HIP library (once) and bind every symbol of the header; fail loudly."""
     global _lib
@@ -90,8 +116,13 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.smplr_abi_version() != 5:
+    if lib.smplr_abi_version() != ABI_VERSION:
         raise RuntimeError("libsmplraster_hip.so ABI version mismatch")
+    want, got = source_build_id(), lib.smplr_build_id().decode("ascii")
+    if want is not None and want != got:
+        raise RuntimeError(
+            "libsmplraster_hip.so was built from other sources than the ones beside it (library %s..., sources "
+            "%s...): rebuild with `make -C indirect_learning_pose-shape_amd/csrc`" % (got[:12], want[:12]))
     _lib = lib
     return lib
 

@@ -204,9 +204,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       vu[q] = project_u(X, c0, c2);
       vv[q] = project_u(Y, c1, c3);
       vz[q] = Z;
-      if (v < VP) {
-        vo[v * 3 + 0] = X; vo[v * 3 + 1] = Y; vo[v * 3 + 2] = Z;
-        po[v * 3 + 0] = vu[q]; po[v * 3 + 1] = vv[q]; po[v * 3 + 2] = Z;
+      if (v < VP) {                                // (either output may be NULL: block-uniform)
+        if (sk.verts) { vo[v * 3 + 0] = X; vo[v * 3 + 1] = Y; vo[v * 3 + 2] = Z; }
+        if (sk.proj) { po[v * 3 + 0] = vu[q]; po[v * 3 + 1] = vv[q]; po[v * 3 + 2] = Z; }
       }
       __builtin_amdgcn_sched_barrier(0);          // one vertex at a time: seven T matrices at once do not fit the registers
     }
@@ -264,8 +264,9 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     __syncthreads();
     SMPLR_TL_STAMP(6);
     vertex1 = s_any_empty && ref_compat && VP > 1;
-    for (int v = tid; v < VP; v += BIN_T)
-      mk[v] = (((vis[v >> 5] >> (v & 31)) & 1u) || (vertex1 && v == 1)) ? 1.0f : 500.0f;
+    if (mask)                                      // (NULL with SKIN when the caller does not want it: block-uniform)
+      for (int v = tid; v < VP; v += BIN_T)
+        mk[v] = (((vis[v >> 5] >> (v & 31)) & 1u) || (vertex1 && v == 1)) ? 1.0f : 500.0f;
   }
   SMPLR_TL_STAMP(7);
   float4 *Gn = G + (size_t)n * S;
@@ -880,7 +881,10 @@ constexpr int SB_U = 8;          // pixels in flight per lane
 // (unconditional: a run that ends has a non-zero sum except by cancellation, and the walk starts on slot 0 with a sum
 // of zero, so the tests that used to guard this - slot valid, sum non-zero - only cost their instructions, in a kernel
 // whose SIMDs are 88 % busy issuing)
+// (cur >= 0 by construction for finite cotangents; a NaN / inf in dseg makes kk of a masked pixel (slot -1) a NaN,
+// which passes `kk != 0`: the max keeps that garbage sum inside the accumulators instead of in front of them)
 __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float sy) {
+  cur = max(cur, 0);
   atomicAdd(&acc[cur * 2], sx);
   atomicAdd(&acc[cur * 2 + 1], sy);
 }
@@ -891,6 +895,7 @@ __device__ __forceinline__ void seg_flush(float *acc, int cur, float sx, float s
 // largest record weight, see seg_bwd_kernel) keeps 2^-41 of the largest possible term as the resolution, far
 // below an fp32 sum's own rounding.
 __device__ __forceinline__ void seg_flush_det(unsigned long long *acc, int cur, float sx, float sy, float scale) {
+  cur = max(cur, 0);
   atomicAdd(&acc[cur * 2], (unsigned long long)__float2ll_rn(sx * scale));
   atomicAdd(&acc[cur * 2 + 1], (unsigned long long)__float2ll_rn(sy * scale));
 }
@@ -1782,6 +1787,19 @@ struct SegWs {
   size_t goff_off, lstart_off, lrec_off, total;
 };
 
+// LDS of the binning workgroup: pixel counters [+ z-buffer keys and visible flags with the fused mask] = base, the
+// vertex -> slot map = slot, and - when it still fits - every vertex' (u, v) (stage).
+struct BinLds { size_t base, slot, total; bool stage; };
+static BinLds bin_lds(int VP, int W, int grid_wh /* 0: mask not fused */, bool with_vslot) {
+  BinLds b;
+  b.base = (size_t)((W * W + 1) & ~1) * sizeof(int);
+  if (grid_wh > 0) b.base += (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
+  b.slot = with_vslot ? ((size_t)VP * 2 + 15) / 16 * 16 : 0;
+  b.stage = b.base + b.slot + (size_t)VP * 8 <= 150 * 1024;
+  b.total = b.base + b.slot + (b.stage ? (size_t)VP * 8 : 0);
+  return b;
+}
+
 // global list (padded per part) + local records + one spare group whose last slot is the header
 static int seg_slots(int P, int K) { return ((K + (GP - 1) * P + 3) / 4 * 4) + (K + 3) / 4 * 4 + GP; }
 
@@ -1816,11 +1834,12 @@ static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fus
                 "%s: bad sizes B=%d VP=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, VP, W, P, K);
   SMPLR_REQUIRE(!fuse_vis || (grid_wh > 0 && grid_wh <= 128), "%s: bad grid_wh=%d (max 128)", fn, grid_wh);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(proj && mask && part_pos && part_off && workspace && rec, "%s: null pointer", fn);
   const bool skin = sk.v_posed != nullptr;
-  SMPLR_REQUIRE(!skin || (sk.top4 && sk.A && sk.cam && sk.x_stride >= 4 && sk.verts && sk.proj == proj && fuse_vis &&
+  // (the skinning form reads v_posed, not proj, and keeps the mask in LDS: there proj, verts and mask are optional outputs)
+  SMPLR_REQUIRE((skin || (proj && mask)) && part_pos && part_off && workspace && rec, "%s: null pointer", fn);
+  SMPLR_REQUIRE(!skin || (sk.top4 && sk.A && sk.cam && sk.x_stride >= 4 && sk.proj == proj && fuse_vis &&
                           VP <= 7 * BIN_T),
-                "%s: the skinning form needs the sparse weights, A, camera rows, verts, proj, the fused mask and V <= %d",
+                "%s: the skinning form needs the sparse weights, A, camera rows, the fused mask and V <= %d",
                 fn, 7 * BIN_T);
   hipStream_t st = as_stream(stream);
   const SegWs ws = seg_ws_layout(B, W, P, K);
@@ -1831,14 +1850,11 @@ static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fus
   int *lstart = reinterpret_cast<int *>(base + ws.lstart_off);
   uint2 *lrec = reinterpret_cast<uint2 *>(base + ws.lrec_off);
   // LDS: pixel counters | fused mask: z-buffer keys + visible flags | staged (u, v) of every vertex
-  size_t lds = (size_t)((W * W + 1) & ~1) * sizeof(int);
-  if (fuse_vis) lds += (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
-  SMPLR_REQUIRE(lds <= 150 * 1024, "%s: pixel counters + grid + flags need %zu B of LDS (max 153600)", fn, lds);
-  const size_t slot_lds = vslot ? ((size_t)VP * 2 + 15) / 16 * 16 : 0;
-  SMPLR_REQUIRE(lds + slot_lds <= 150 * 1024, "%s: LDS budget exceeded (%zu B)", fn, lds + slot_lds);
-  const bool stage = lds + slot_lds + (size_t)VP * 8 <= 150 * 1024;
-  if (stage) lds += (size_t)VP * 8;
-  lds += slot_lds;
+  const BinLds bl = bin_lds(VP, W, fuse_vis ? grid_wh : 0, vslot != nullptr);
+  SMPLR_REQUIRE(bl.base <= 150 * 1024, "%s: pixel counters + grid + flags need %zu B of LDS (max 153600)", fn, bl.base);
+  SMPLR_REQUIRE(bl.base + bl.slot <= 150 * 1024, "%s: LDS budget exceeded (%zu B)", fn, bl.base + bl.slot);
+  const bool stage = bl.stage;
+  const size_t lds = bl.total;
 #define SMPLR_BIN_LAUNCH(VIS_, STAGE_, SKIN_)                                                                 \
   {                                                                                                           \
     int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<VIS_, STAGE_, SKIN_>), lds);          \
@@ -1916,12 +1932,18 @@ int smplr_vis_seg_fwd(const float *proj, int B, int VP, int W, int grid_wh, int 
                              part_off, P, K, workspace, seg, arg, rec, vslot, stream);
 }
 
+int smplr_skin_vis_seg_fits(int V, int W, int grid_wh) {
+  if (V <= 0 || V > 7 * smplr::BIN_T || W <= 0 || W > 160 || grid_wh <= 0 || grid_wh > 128) return 0;
+  const smplr::BinLds b = smplr::bin_lds(V, W, grid_wh, true);
+  return (b.base + b.slot <= 150 * 1024 && b.stage) ? 1 : 0;
+}
+
 int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam, int x_stride,
                            int B, int V, int W, int grid_wh, int ref_compat, const int32_t *part_pos,
                            const int32_t *part_off, int P, int K, void *workspace, float *verts, float *proj,
                            float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B <= 0 || (v_posed && lbs_top4 && A && cam && verts && proj), "smplr_skin_vis_seg_fwd: null pointer");
+  SMPLR_REQUIRE(B <= 0 || (v_posed && lbs_top4 && A && cam), "smplr_skin_vis_seg_fwd: null pointer");
   const SkinIn sk{v_posed, lbs_top4, A, cam, x_stride, verts, proj};
   int rc = seg_bin_impl("smplr_skin_vis_seg_fwd", proj, mask, true, grid_wh, ref_compat, B, V, W, part_pos, part_off, P,
                         K, workspace, rec, vslot, stream, sk);

@@ -335,6 +335,9 @@ def _skin_vis_seg_fwd(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, grid_
     B, V = v_posed.shape[0], c.V
     if c.lbs_top4 is None or pt.VP != V:
         raise RuntimeError("_skin_vis_seg_fwd needs <= 4 skinning weights per vertex and vertex_sampling = 1")
+    if not lib.smplr_skin_vis_seg_fits(V, int(W), int(grid_wh)):
+        raise RuntimeError("_skin_vis_seg_fwd: V=%d, W=%d, grid_wh=%d do not fit the binning workgroup's LDS "
+                           "(smplr_skin_vis_seg_fits): call _skin_fwd and _vis_seg_fwd" % (V, W, grid_wh))
     ws = _workspace(lib.smplr_seg_workspace(B, V, W, pt.P, pt.K), v_posed)
     if out is not None:
         verts, proj, mask, seg, arg, rec = out
@@ -835,7 +838,7 @@ class DecoderFn(torch.autograd.Function):
 
         # the binning workgroups skin their own vertices (one launch less) when the skinning rows are sparse, every
         # vertex is rasterised and a mesh fits one trip of the binning kernel; SMPLR_FUSE_SKIN=0 keeps the two calls
-        fuse_skin = (consts.lbs_top4 is not None and vs == 1 and V <= 7168 and 0 < grid_wh <= 128
+        fuse_skin = (consts.lbs_top4 is not None and vs == 1 and bool(lib.smplr_skin_vis_seg_fits(V, W, int(grid_wh)))
                      and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
 
         def run(lo, hi):

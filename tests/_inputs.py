@@ -11,3 +11,61 @@ def make_x(B, W, seed=0, theta_sigma=0.2, beta_sigma=1.0):
     x[:, 4:76] += rng.normal(0.0, theta_sigma, (B, 72))
     x[:, 76:86] += rng.normal(0.0, beta_sigma, (B, 10))
     return x.astype(np.float32)
+
+
+def argmin_disagreements(a, warg, want, proj, mask, W, rtol=1e-5):
+    """The arg-min identity test with a CAUSE instead of a fraction.  a / warg (B, W, W, P): the maximising
+    vertex per (pixel, part) from the HIP path and from the float64 oracle (-1: none); want (B, W, W, 1 + P): the
+    oracle's scores; proj (B, V', 3), mask (B, V'): what both were given.  fp32 and float64 may only disagree on a
+    NEAR-TIE: the vertex the HIP path picked must reach, in float64, within `rtol` (relative, in the exponent
+    m d) of the oracle's minimum - or the score is underflowed (< 1e-30), where any vertex gives exactly 0.
+    Returns (number of disagreements, number of unexplained ones); the caller asserts the second is 0."""
+    a, warg = np.asarray(a, np.int64), np.asarray(warg, np.int64)
+    proj, mask = np.asarray(proj, np.float64), np.asarray(mask, np.float64)
+    diff = (a != warg) & (np.asarray(want)[..., 1:] >= 1e-30)
+    idx = np.argwhere(diff)
+    bad = 0
+    for n, ro, c, p in idx:
+        va, vw = a[n, ro, c, p], warg[n, ro, c, p]
+        if va < 0 or vw < 0:
+            bad += 1
+            continue
+        r = W - 1 - ro                                            # rows are flipped on output
+        da = mask[n, va] * np.hypot(proj[n, va, 0] - c, proj[n, va, 1] - r)
+        dw = mask[n, vw] * np.hypot(proj[n, vw, 0] - c, proj[n, vw, 1] - r)
+        if not (da <= dw * (1.0 + rtol) + 1e-9):
+            bad += 1
+    return len(idx), bad
+
+
+def unstable_cells(proj, grid_wh=64, eps=1e-4, zeps=1e-5):
+    """Cells of the visibility grid whose winner may differ between fp32 and float64 vertices, by cause: a vertex
+    within `eps` px of a cell border (it may round into either cell - both are marked), or the two largest depths
+    of a cell within `zeps`.  proj (V', 3) float64 -> bool (grid_wh, grid_wh) indexed [row (v), column (u)]."""
+    proj = np.asarray(proj, np.float64)
+    out = np.zeros((grid_wh, grid_wh), bool)
+    u, v, z = proj[:, 0], proj[:, 1], proj[:, 2]
+
+    def mark(cu, cv):
+        ok = (cu >= 0) & (cu < grid_wh) & (cv >= 0) & (cv < grid_wh)
+        out[cv[ok].astype(int), cu[ok].astype(int)] = True
+
+    fu, fv = np.abs(u - np.floor(u) - 0.5), np.abs(v - np.floor(v) - 0.5)
+    near = (fu < eps) | (fv < eps)
+    for du in (-eps, eps):
+        for dv in (-eps, eps):
+            mark(np.rint(u[near] + du), np.rint(v[near] + dv))
+    cu, cv = np.rint(u), np.rint(v)
+    ok = (cu >= 0) & (cu < grid_wh) & (cv >= 0) & (cv < grid_wh)
+    cell = (cv[ok] * grid_wh + cu[ok]).astype(int)
+    zz = z[ok]
+    order = np.lexsort((-zz, cell))
+    cs, zs = cell[order], zz[order]
+    same = cs[1:] == cs[:-1]
+    first = np.r_[True, ~same]                                    # first (deepest-z) entry of each cell
+    second = np.r_[False, first[:-1]] & np.r_[False, same]        # the entry right after it, same cell
+    tie = np.zeros(len(cs), bool)
+    tie[1:] = second[1:] & (np.abs(zs[1:] - zs[:-1]) < zeps)
+    tc = cs[tie]
+    out[tc // grid_wh, tc % grid_wh] = True
+    return out

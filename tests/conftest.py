@@ -16,19 +16,29 @@ def pytest_configure(config):
 
 
 def _ensure_built():
-    """The shared library is git-ignored: (re)build it in-tree when missing or older than its sources
-    (hipcc cross-compiles gfx950 without a GPU).  Building the product is not a fallback: every op
-    still fails loudly if the library cannot be loaded."""
-    import glob
+    """The shared library is git-ignored: (re)build it in-tree when it is missing or was NOT built from the
+    sources beside it - decided by the build id compiled into it (sha256 of csrc/*.hip, csrc/*.h and the header),
+    not by file times, which a copy to another box can equalise (hipcc cross-compiles gfx950 without a GPU).
+    Building the product is not a fallback: every op still fails loudly if the library cannot be loaded, and
+    `_lib.load()` itself refuses a library whose id differs from its sources."""
+    import ctypes
     import subprocess
-    pkg = os.path.join(ROOT, "indirect_learning_pose-shape_amd")
-    lib = os.path.join(pkg, "libsmplraster_hip.so")
-    srcs = glob.glob(os.path.join(pkg, "csrc", "*.hip")) + glob.glob(os.path.join(pkg, "csrc", "*.h")) + \
-        [os.path.join(ROOT, "include", "smplraster.h")]
-    stale = (not os.path.exists(lib)) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs)
-    if stale:
-        subprocess.run(["make", "-C", os.path.join(pkg, "csrc"), "-j4"], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+    from ilps_amd import _lib
+    csrc = os.path.join(ROOT, "indirect_learning_pose-shape_amd", "csrc")
+
+    def built_id():
+        if not os.path.exists(_lib.LIB_PATH):
+            return None
+        try:
+            fn = ctypes.CDLL(_lib.LIB_PATH).smplr_build_id
+        except (OSError, AttributeError):
+            return None
+        fn.restype = ctypes.c_char_p
+        return fn().decode("ascii")
+
+    if built_id() != _lib.source_build_id():
+        subprocess.run(["make", "-C", csrc, "-B", "-j4"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.STDOUT)
 
 
 _ensure_built()

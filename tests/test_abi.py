@@ -37,7 +37,7 @@ def test_ctypes_table_matches_header():
     from ilps_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     lib = _lib.load()
-    assert lib.smplr_abi_version() == 5
+    assert lib.smplr_abi_version() == _lib.ABI_VERSION == 6
     # argument errors are reported without touching the GPU
     rc = lib.smplr_visibility(None, 1, 6890, 0, 1, None, None)
     assert rc == -1 and b"grid_wh" in lib.smplr_last_error()
@@ -49,6 +49,11 @@ def test_ctypes_table_matches_header():
     assert lib.smplr_skin_vis_seg_fwd(None, None, None, None, 86, 0, 6890, 48, 64, 1, None, None, 31, 6879, None, None,
                                       None, None, None, None, None, None, None) == 0
     assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 27 * 292 * 4
+    # the skinning form of the binning kernel needs the mesh's staged (u, v) in LDS beside the 64 x 64 z-buffer, the
+    # pixel counters and the slot map: it fits the reference's raster sizes, not the largest ones the ABI accepts
+    assert lib.smplr_skin_vis_seg_fits(6890, 48, 64) == 1 and lib.smplr_skin_vis_seg_fits(6890, 96, 64) == 1
+    assert lib.smplr_skin_vis_seg_fits(6890, 128, 64) == 0 and lib.smplr_skin_vis_seg_fits(6890, 160, 64) == 0
+    assert lib.smplr_skin_vis_seg_fits(7169, 48, 64) == 0 and lib.smplr_skin_vis_seg_fits(6890, 48, 0) == 0
 
 
 def test_argument_counts_match_header():
@@ -74,3 +79,24 @@ def test_seg_bwd_row_blocks_by_batch():
     assert lib.smplr_seg_bwd_nsplit(300, 20) == 1 and lib.smplr_seg_bwd_nsplit(0, 48) == 0
     for B, W in ((1, 48), (128, 48), (64, 96), (5, 50)):
         assert lib.smplr_seg_bwd_workspace(B, W) == B * lib.smplr_seg_bwd_nsplit(B, W) * 5 * 4096 * 2 * 4
+
+
+def test_library_is_built_from_the_sources_beside_it(monkeypatch):
+    """smplr_build_id() = sha256 over csrc/*.hip, csrc/*.h and the header as csrc/Makefile took it; `_lib.load()`
+    recomputes it from the files and refuses a library built from anything else."""
+    import subprocess
+    from ilps_amd import _lib
+    want = _lib.source_build_id()
+    assert want is not None and len(want) == 64
+    assert _lib.build_id() == want
+    # the Makefile's recipe, spelled out independently: cat of the sorted sources + the header | sha256sum
+    csrc = os.path.join(ROOT, "indirect_learning_pose-shape_amd", "csrc")
+    names = sorted(f for f in os.listdir(csrc) if f.endswith(".hip") or f.endswith(".h"))
+    sh = subprocess.run("cat %s ../../include/smplraster.h | sha256sum" % " ".join(names), shell=True, cwd=csrc,
+                        stdout=subprocess.PIPE, check=True).stdout.decode().split()[0]
+    assert sh == want
+    # a library whose id differs from the sources' is refused at load
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_build_id", lambda: "0" * 64)
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        _lib.load()

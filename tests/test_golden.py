@@ -40,8 +40,10 @@ def test_oracle_reproduces_golden(path, smpl_model, part_tables):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
-def test_hip_matches_golden(path, smpl_model):
+def test_hip_matches_golden(path, smpl_model, part_tables):
     from ilps_amd.decoder import SMPLDecoder
+    from oracle import np_oracle as o
+    from _inputs import unstable_cells
     W, vs = _cfg(path)
     z = np.load(path)
     dev = torch.device("cuda:0")
@@ -53,12 +55,28 @@ def test_hip_matches_golden(path, smpl_model):
     assert np.abs(out["J_transformed"].detach().cpu().numpy() - z["J_transformed"]).max() <= 1e-4
     vis = (out["mask"].cpu().numpy() == 1.0)
     want_vis = np.unpackbits(z["mask_visible"], axis=1)[:, :vis.shape[1]].astype(bool)
-    # fp32 vertices differ from the float64 oracle's by ~1e-6 px: a handful of vertices may round
-    # to the other pixel; everything else must agree exactly
-    assert (vis != want_vis).mean() < 2e-3
+    # fp32 vertices differ from the float64 oracle's by ~1e-6 px, so a vertex' visibility may differ from the golden
+    # one for ONE reason only: its cell of the 64 x 64 grid is unstable - some vertex lies within 1e-4 px of that
+    # cell's border (it rounds into either cell) or the cell's two largest depths are within 1e-5.  No fraction.
+    x64 = z["x"].astype(np.float64)
+    proj64 = o.orthographic_project(o.smpl_layer_call(x64, smpl_model), x64, vs)
+    n_mism = 0
+    for n in range(vis.shape[0]):
+        unst = unstable_cells(proj64[n])
+        for v in np.nonzero(vis[n] != want_vis[n])[0]:
+            cu, cv = int(np.rint(proj64[n, v, 0])), int(np.rint(proj64[n, v, 1]))
+            assert 0 <= cu < 64 and 0 <= cv < 64 and unst[cv, cu], \
+                "mesh %d vertex %d: visibility differs from the golden mask in a stable cell (%d, %d)" % (n, v, cu, cv)
+            n_mism += 1
+    print("visibility: %d vertices differ from the golden mask, all in unstable cells" % n_mism)
+    # scores: EVERY entry within the bar of the oracle's scores for the visibility the HIP path found (the golden
+    # scores themselves wherever that is the golden visibility); 1e-4 absolute: a hidden vertex' exp(-500 d) turns a
+    # 1e-6 px shift of the fp32 vertices into 5e-4 relative
     seg, want = out["seg"].detach().cpu().numpy(), z["seg"]
-    close = np.abs(seg - want) <= 1e-3 * np.abs(want) + 1e-4
-    assert close.mean() > 0.999
+    ids, off = part_tables[vs or 1]
+    if n_mism:
+        want = o.projects_to_seg(proj64, np.where(vis, 1.0, 500.0), W, ids, off, vs)
+    assert np.all(np.abs(seg - want) <= 1e-3 * np.abs(want) + 1e-4)
     rng = np.random.default_rng(W)
     gs = torch.tensor(rng.normal(0, 1, want.shape).astype(np.float32), device=dev)
     if with_silh:

@@ -186,6 +186,61 @@ def test_config3_train_step_B256(smpl_model):
     assert np.abs(full["verts"][ROWS_256].cpu().numpy() - ref).max() <= VERT_ATOL
 
 
+def test_config4_train_step_with_silhouette_B128(smpl_model):
+    """BASELINE configs[4]'s per-GPU train step: SegTrainer(with_silhouette=True).step at 128 images per GPU
+    (ENet on 256x256 inputs + IEF + decoder with BOTH heads at 48x48 + softmax-focal loss + silhouette
+    cross-entropy + Adam; train_stage2_silhouette.py:226-234).  Finite losses and gradients, and the loss on a
+    fixed batch drops over 3 steps."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.smpl_model import mean86
+    from ilps_amd.training import SegTrainer
+    torch.manual_seed(1)
+    dev = torch.device("cuda:0")
+    B, W = 128, 48
+    tr = SegTrainer(smpl_model, output_wh=W, encoder_architecture="enet", use_IEF=True, lr=1e-4, device=dev,
+                    with_silhouette=True)
+    tr.smpl_model.train()
+    images = torch.rand(B, 3, 256, 256, device=dev)
+    xl = torch.tensor(np.tile(mean86(W), (B, 1)), dtype=torch.float32, device=dev)
+    xl[:, 4:76] += 0.1 * torch.randn(B, 72, device=dev)
+    with torch.no_grad():
+        tgt = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=True)(xl)
+        labels, silh_labels = tgt["seg"].argmax(-1), tgt["silhouette"].argmax(-1)
+    assert silh_labels.shape == (B, W, W) and int(silh_labels.sum()) > 0
+    losses = [float(tr.step(images, labels, silh_labels)) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    grads = [p.grad for p in tr.smpl_model.parameters() if p.grad is not None]
+    assert len(grads) > 100 and all(bool(torch.isfinite(g).all()) for g in grads)
+    assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("W", [112, 128, 160])
+def test_decoder_at_large_raster_sizes(smpl_model, part_tables, W):
+    """The skinning form of the binning kernel keeps the mesh's (u, v) in LDS beside the pixel counters: it fits up
+    to W = 112 at V = 6890 (smplr_skin_vis_seg_fits); beyond, the decoder takes the two-call path (smplr_skin_fwd
+    + smplr_vis_seg_fwd) by itself.  Either way: vertices, mask and every score against the float64 oracle."""
+    from ilps_amd import _lib
+    from ilps_amd.decoder import SMPLDecoder
+    from oracle import np_oracle as o
+    assert bool(_lib.load().smplr_skin_vis_seg_fits(6890, W, 64)) == (W <= 112)
+    B = 2
+    x = make_x(B, W, seed=W)
+    dev = torch.device("cuda:0")
+    xg = torch.tensor(x, device=dev, requires_grad=True)
+    out = SMPLDecoder(smpl_model, img_wh=W)(xg)
+    out["seg"].square().sum().backward()
+    assert bool(torch.isfinite(xg.grad).all()) and float(xg.grad.abs().sum()) > 0
+    ref_v = o.smpl_layer_call(x.astype(np.float64), smpl_model)
+    assert np.abs(out["verts"].detach().cpu().numpy() - ref_v).max() <= VERT_ATOL
+    pj = out["projects"].detach().cpu().numpy().astype(np.float64)
+    ref_m = o.compute_mask(pj)
+    assert np.array_equal(ref_m, out["mask"].cpu().numpy())
+    ids, off = part_tables[1]
+    want = o.projects_to_seg(pj, ref_m, W, ids, off)
+    got = out["seg"].detach().cpu().numpy()
+    assert np.all(np.abs(got - want) <= 1e-3 * np.abs(want) + 1e-6)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second HIP device")
 def test_ops_follow_their_operands_device(smpl_model):
     """Operands on cuda:1 while cuda:0 is the current device: the launches must go to the operands' device

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _inputs import make_x
+from _inputs import argmin_disagreements, make_x
 
 pytestmark = pytest.mark.gpu
 
@@ -175,10 +175,11 @@ def test_seg_forward(layer, part_tables, W, vs):
     got = seg.cpu().numpy()
     assert got.shape == (2, W, W, 32)
     assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
-    # arg-min identity wherever the score is not underflowed/tied (fp32 vs fp64 can differ on ties)
-    a = arg.cpu().numpy().astype(np.int64)
-    agree = (a == warg) | (want[..., 1:] < 1e-30)
-    assert agree.mean() > 0.999
+    # arg-min identity, except on near-ties: where the two differ, the vertex the HIP path picked reaches, in
+    # float64, within 1e-5 (relative, in the exponent) of the oracle's minimum - every disagreement is checked
+    ndiff, bad = argmin_disagreements(arg.cpu().numpy(), warg, want, proj.cpu().numpy(), mask.cpu().numpy(), W)
+    assert bad == 0, "%d of %d arg-min disagreements are not near-ties" % (bad, ndiff)
+    assert ndiff <= 64, "%d arg-min disagreements: near-ties are rare (a handful per mesh)" % ndiff
 
 
 def test_seg_kats(part_tables):
@@ -303,7 +304,7 @@ def test_decoder_end_to_end(smpl_model, part_tables, with_silh):
     assert np.abs(out["verts"].detach().cpu().numpy() - vo.detach().numpy()).max() <= VERT_ATOL
     sg, sw = out["seg"].detach().cpu().numpy(), so.detach().numpy()
     # end to end the fp32 vertices move by ~1e-6 px, so allow that on top of the 1e-3 rel bar
-    assert np.mean(np.abs(sg - sw) <= SEG_RTOL * np.abs(sw) + 1e-4) > 0.9999
+    assert np.all(np.abs(sg - sw) <= SEG_RTOL * np.abs(sw) + 1e-4)
     got, want = xg.grad.cpu().numpy(), xo.grad.numpy()
     for sl, name in ((slice(0, 4), "dcam"), (slice(4, 76), "dtheta"), (slice(76, 86), "dbeta")):
         grad_close(got[:, sl], want[:, sl], 5e-3, name)
@@ -331,6 +332,9 @@ def test_native_library_loaded():
     _lib.load()
     maps = open("/proc/self/maps").read()
     assert "libsmplraster_hip.so" in maps
+    # ... and it was built from the sources that travelled with it (sha256 of csrc/*.hip, csrc/*.h, the header)
+    assert _lib.build_id() == _lib.source_build_id()
+    print("libsmplraster_hip.so build id", _lib.build_id())
 
 
 def test_concurrent_chunks_identical(smpl_model):
@@ -589,9 +593,9 @@ def test_seg_record_list_regimes(layer, part_tables, W, nfar, unit):
     want, warg = o.projects_to_seg(proj.cpu().numpy().astype(np.float64), m, W, ids, off, return_argmin=True)
     got = seg.cpu().numpy()
     assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
-    a = arg.cpu().numpy().astype(np.int64)
-    agree = (a == warg) | (want[..., 1:] < 1e-30)
-    assert agree.mean() > 0.999
+    ndiff, bad = argmin_disagreements(arg.cpu().numpy(), warg, want, proj.cpu().numpy(), m, W)
+    assert bad == 0, "%d of %d arg-min disagreements are not near-ties" % (bad, ndiff)
+    assert ndiff <= 64, "%d arg-min disagreements: near-ties are rare (a handful per mesh)" % ndiff
 
 
 @pytest.mark.parametrize("P,VP,W,B", [(1, 64, 24, 3), (5, 300, 40, 9), (17, 1000, 48, 2), (31, 500, 20, 11)])
