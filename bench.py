@@ -361,6 +361,98 @@ def launch_ranks(n, argv):
     return proc.returncode
 
 
+def _max_over_ranks(dist, v, dev, backend):
+    if dist is None:
+        return v
+    tt = torch.tensor([v], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def _timed_steps(fn, warm, steps, dist, dev, backend, sync):
+    """`steps` calls of fn bracketed by barrier + synchronize on both sides, MAX over ranks -> seconds."""
+    for _ in range(warm):
+        fn()
+    sync()
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    sync()
+    if dist:
+        dist.barrier()
+    sync()
+    return _max_over_ranks(dist, time.perf_counter() - t0, dev, backend)
+
+
+def train_leg(args, rank, world, dev, dist, backend, model, W):
+    """The data-parallel TRAIN step of BASELINE configs[3]/[4] (train.py:205-215,
+    train_stage2_silhouette.py:226-234): ENet(256x256x3) + IEF + HIP decoder with both heads + softmax-focal loss +
+    silhouette cross-entropy + Adam, `--train-batch` images per GPU, DistributedDataParallel over RCCL when world > 1
+    - the design's ONE collective (the gradient all-reduce of the encoder + regressor: `allreduce_MiB` per step).
+    Every rank runs it (rank-synchronous); rank 0 gets the dict.  Legs, each barrier-bracketed and MAX-reduced:
+      ddp                 the step as trained (all-reduce overlapped with backward by DDP's buckets)
+      no_sync             the same step inside `no_sync()`: no all-reduce - the difference is what the collective costs
+      strong_global_G     the step at G / world images per GPU (G = --train-global-batch, 1024: the strong-scaling point)"""
+    import contextlib
+    from ilps_amd.training import SegTrainer
+    per = int(args.train_batch)
+    steps, warm = int(args.train_steps), 3
+    sync = torch.cuda.synchronize
+    torch.manual_seed(1234)                                  # same initial weights on every rank (DDP broadcasts anyway)
+    tr = SegTrainer(model, output_wh=W, encoder_architecture="enet", use_IEF=True, device=dev, ddp=world > 1,
+                    with_silhouette=True)
+    tr.smpl_model.train()
+    nparam = sum(p.numel() for p in tr.smpl_model.parameters() if p.requires_grad)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)
+
+    def batch(n):
+        return (torch.rand(n, 3, 256, 256, device=dev, generator=gen),
+                torch.randint(0, 32, (n, W, W), device=dev, generator=gen),
+                torch.randint(0, 2, (n, W, W), device=dev, generator=gen))
+
+    out = {"workload": "train step: ENet(256x256x3) + IEF + decoder(W=%d, seg + silhouette) + softmax-focal loss + "
+                       "silhouette CE + Adam; BASELINE configs[3]/[4]" % W,
+           "images_per_gpu": per, "global_batch": per * world, "n_gpus": world, "steps": steps, "warmup": warm,
+           "ddp": world > 1, "backend": (backend if world > 1 else None),
+           "params": int(nparam), "allreduce_MiB": round(nparam * 4 / 2 ** 20, 1) if world > 1 else 0.0,
+           "bucket_MiB": 25, "scaling": "weak"}
+    data = batch(per)
+    el = _timed_steps(lambda: tr.step(*data), warm, steps, dist, dev, backend, sync)
+    out["ddp_step" if world > 1 else "step"] = {"ms_per_step": round(el / steps * 1e3, 3),
+                                                "images_per_s": round(world * per * steps / el, 1)}
+    out["images_per_s"] = round(world * per * steps / el, 1)
+    out["ms_per_step"] = round(el / steps * 1e3, 3)
+    if world > 1:
+        def nosync_step():
+            with tr.net.no_sync():
+                tr.step(*data)
+        el2 = _timed_steps(nosync_step, 1, steps, dist, dev, backend, sync)
+        out["no_sync_step"] = {"ms_per_step": round(el2 / steps * 1e3, 3),
+                               "images_per_s": round(world * per * steps / el2, 1),
+                               "note": "same step without the gradient all-reduce (DDP.no_sync)"}
+        out["allreduce_exposed_ms"] = round((el - el2) / steps * 1e3, 3)
+        G = int(args.train_global_batch)
+        if G % world == 0 and G // world <= 512 and G // world != per:
+            try:
+                ps = G // world
+                del data
+                data_s = batch(ps)
+                el3 = _timed_steps(lambda: tr.step(*data_s), 2, steps, dist, dev, backend, sync)
+                out["strong_global_%d" % G] = {"images_per_gpu": ps, "ms_per_step": round(el3 / steps * 1e3, 3),
+                                               "images_per_s": round(G * steps / el3, 1), "scaling": "strong"}
+                del data_s
+            except Exception as e:          # (an out-of-memory on one rank would desynchronise the others: reported, not hidden)
+                out["strong_global_%d" % G] = {"error": str(e)}
+        elif G // world == per:
+            out["strong_global_%d" % G] = {"images_per_gpu": per, "same_as": "ddp_step", "scaling": "strong"}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def dry_run(args, rank, world):
     """`--dry-run`: the N-rank protocol of the bench without a GPU (gloo): per-rank seeded inputs, a CPU stand-in
     step (parameter conditioning of the rank's own meshes + a rank-dependent sleep), barrier-bracketed timing,
@@ -396,14 +488,47 @@ def dry_run(args, rank, world):
         rows = [torch.zeros(4, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(rows, torch.tensor([seed, mine, sums[0], work], dtype=torch.float64))
         seeds, times, sums, works = ([float(r[i]) for r in rows] for i in range(4))
+    # the train leg's protocol on CPU: a stand-in regressor (the real one's IEF head on random features) under
+    # DistributedDataParallel over gloo - ddp step, no_sync step, all-reduce volume - same keys as the GPU leg
+    tleg = None
+    if not args.no_train_leg:
+        import contextlib
+        from torch import nn
+        torch.manual_seed(7)
+        net = nn.Sequential(nn.Linear(64, 128), nn.ReLU(), nn.Linear(128, 86))
+        ddp = nn.parallel.DistributedDataParallel(net) if world > 1 else net
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        feats = torch.randn(int(args.train_batch), 64, generator=torch.Generator().manual_seed(100 + rank))
+
+        def tstep(ctx=contextlib.nullcontext):
+            with ctx():
+                opt.zero_grad(set_to_none=True)
+                ddp(feats).square().mean().backward()
+                opt.step()
+        dmod = dist if world > 1 else None
+        el1 = _timed_steps(tstep, 1, args.train_steps, dmod, "cpu", "gloo", lambda: None)
+        nparam = sum(p.numel() for p in net.parameters())
+        tleg = {"workload": "DRY RUN stand-in (CPU MLP under DDP/gloo): protocol only", "stand_in": True,
+                "images_per_gpu": int(args.train_batch), "global_batch": int(args.train_batch) * world, "n_gpus": world,
+                "steps": args.train_steps, "ddp": world > 1, "backend": "gloo" if world > 1 else None,
+                "params": nparam, "allreduce_MiB": round(nparam * 4 / 2 ** 20, 4) if world > 1 else 0.0, "scaling": "weak",
+                "images_per_s": round(world * args.train_batch * args.train_steps / el1, 1),
+                "ms_per_step": round(el1 / args.train_steps * 1e3, 3)}
+        tleg["ddp_step" if world > 1 else "step"] = {"ms_per_step": tleg["ms_per_step"], "images_per_s": tleg["images_per_s"]}
+        if world > 1:
+            el2 = _timed_steps(lambda: tstep(ddp.no_sync), 1, args.train_steps, dmod, "cpu", "gloo", lambda: None)
+            tleg["no_sync_step"] = {"ms_per_step": round(el2 / args.train_steps * 1e3, 3),
+                                    "images_per_s": round(world * args.train_batch * args.train_steps / el2, 1)}
+            tleg["allreduce_exposed_ms"] = round((el1 - el2) / args.train_steps * 1e3, 3)
     if rank == 0:
         print(json.dumps({
             "metric": "meshes/sec fwd+bwd (SMPL->48x48 31-part seg)", "value": round(world * B * args.steps / elapsed, 1),
             "unit": "meshes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "dry_run": True,
             "config": {"workload": "DRY RUN (no GPU): launcher / sharding / timing protocol only",
                        "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W},
+            "train_step": tleg,
             "rank_seeds": [int(v) for v in seeds], "rank_elapsed_s": times, "rank_work_s": works,
             "rank_input_checksums": sums}), flush=True)
     if world > 1:
@@ -423,6 +548,15 @@ def main():
                     help="concurrent mesh chunks per step (HIP streams / parallel graph branches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch meshes per GPU (default); strong: --global-batch meshes split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=1024, help="strong scaling: total meshes, split evenly")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the (data-parallel) train-step leg")
+    ap.add_argument("--train-batch", type=int, default=128, help="train leg: images per GPU")
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-global-batch", type=int, default=1024,
+                    help="train leg, world > 1: the fixed global batch of its strong-scaling point (configs[4]: 1024)")
+    ap.add_argument("--windows", type=int, default=10, help="timed windows of --steps for the min/median/max spread")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: run the N-rank launch / timing protocol over gloo with a CPU stand-in step")
     args = ap.parse_args()
@@ -438,6 +572,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree "
                          "(python -m torch.distributed.run --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            raise SystemExit("bench.py: --global-batch %d does not split over %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
     if args.dry_run:
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
@@ -512,6 +650,19 @@ def main():
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # the spread: further windows of the same K steps, same bracketing (the first window above is `value`)
+    windows = [elapsed / args.steps * 1e3]
+    for _ in range(max(0, args.windows - 1)):
+        windows.append(_timed_steps(run, 0, args.steps, dist, dev, backend, torch.cuda.synchronize) / args.steps * 1e3)
+    # the design's one collective: the data-parallel train step (every rank takes part)
+    tleg = None
+    if not args.no_train_leg:
+        try:
+            tleg = train_leg(args, rank, world, dev, dist, backend, model, W)
+        except Exception as e:
+            if world > 1:
+                raise                       # ranks would desynchronise: fail the run loudly
+            tleg = {"error": str(e)}
 
     line = None
     if rank == 0:
@@ -521,7 +672,12 @@ def main():
             "metric": "meshes/sec fwd+bwd (SMPL->48x48 31-part seg)",
             "value": round(value, 1), "unit": "meshes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_windows": {"n": len(windows), "steps_each": args.steps, "min": round(min(windows), 4),
+                                    "median": round(float(np.median(windows)), 4), "max": round(max(windows), 4),
+                                    "note": "the first window is `ms_per_step` / `value`; boxes differ by +-4 %"},
+            "build_id": _lib.build_id(),
+            "train_step": tleg,
             "config": {"workload": "full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
                                    "projects_to_seg), BASELINE configs[2]",
                        "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,

@@ -182,6 +182,22 @@ __device__ __forceinline__ Frag3 split8(const float x[8]) {
   return f;
 }
 
+// ---- focal loss pieces shared by the loss head (loss.hip) and the rasteriser's loss epilogue (raster.hip) ----
+constexpr float K_EPS = 1e-7f;   // keras.backend.epsilon()  (focal_loss.py:17)
+__device__ __forceinline__ float pow_gamma(float x, float gamma) {
+  // (1-p)^gamma; the reference's only values are 2 (focal) and, for cross-entropy, 0
+  if (gamma == 2.0f) return x * x;
+  if (gamma == 0.0f) return 1.0f;
+  if (gamma == 1.0f) return x;
+  return powf(x, gamma);
+}
+__device__ __forceinline__ float dpow_gamma(float x, float gamma) {   // d/dx x^gamma
+  if (gamma == 2.0f) return 2.0f * x;
+  if (gamma == 0.0f) return 0.0f;
+  if (gamma == 1.0f) return 1.0f;
+  return gamma * powf(x, gamma - 1.0f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

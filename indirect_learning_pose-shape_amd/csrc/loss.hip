@@ -16,22 +16,6 @@
 
 namespace smplr {
 
-constexpr float K_EPS = 1e-7f;   // keras.backend.epsilon()
-
-__device__ __forceinline__ float pow_gamma(float x, float gamma) {
-  // (1-p)^gamma; the reference's only values are 2 (focal) and, for cross-entropy, 0
-  if (gamma == 2.0f) return x * x;
-  if (gamma == 0.0f) return 1.0f;
-  if (gamma == 1.0f) return x;
-  return powf(x, gamma);
-}
-__device__ __forceinline__ float dpow_gamma(float x, float gamma) {   // d/dx x^gamma
-  if (gamma == 2.0f) return 2.0f * x;
-  if (gamma == 0.0f) return 0.0f;
-  if (gamma == 1.0f) return 1.0f;
-  return gamma * powf(x, gamma - 1.0f);
-}
-
 template <int GL>
 __device__ __forceinline__ float group_max(float v) {
 #pragma unroll

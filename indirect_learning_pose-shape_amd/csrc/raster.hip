@@ -606,13 +606,22 @@ __device__ __forceinline__ float sum8_dpp(float v) {
 // fixed group of 8 channels differ several-fold: a torso facing the camera against a hidden arm).
 // Scores meet in a pixel-major LDS tile; after one barrier all 16 waves write it out, and the
 // background channel comes from the sum over the tile row (fixed tree, independent of the cuts).
+// LOSS: the loss head's forward as the epilogue (model.py:119-120 Reshape + softmax, focal_loss.py:10-46 at an integer
+// class map): a pixel's 32 raw scores sit in 8 adjacent lanes at write-out time, so its softmax denominator, the
+// labelled class' probability and the per-pixel loss cost two 8-lane tree sums - and the (B, W, W, 32) score tensor
+// need not be written at all (seg = NULL): the backward (seg_bwd_kernel<.., LOSS>) rebuilds d loss / d score of every
+// channel from 16 bytes per pixel left here (`stats`: 1 / sum exp(score), sign = the clip's gate | background score |
+// q_t softmax_t | label) instead of reading a 128-B row of dseg.  Scores lie in [0, 1]: the softmax needs no max shift.
+struct LossOut { const int *labels; const float *class_w; float gamma; float *loss; float4 *stats; };
+
+template <bool LOSS>
 __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
                                                              const int *__restrict__ goff,
                                                              const int *__restrict__ lstart,
                                                              const uint2 *__restrict__ lrec, int P, int K,
                                                              int S, int W, int B, int ntiles,
                                                              float *__restrict__ seg, short *__restrict__ arg,
-                                                             unsigned wmagic) {
+                                                             unsigned wmagic, LossOut lo) {
   __shared__ float sS[RTS * SLD];
   __shared__ short sA[RTS * ALD];
   __shared__ f32x4 sRec[ARENA / 4];      // records, field-major: u[NREC] | v[NREC] | m^2[NREC]; row tables
@@ -644,12 +653,19 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   constexpr int NIT = 8 / NG;
   const int sub = tid & 7;
   int l0a[NIT], l1a[NIT];
+  int lab[NIT];                                          // LOSS: the label of each of this lane's merge pixels
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int qq = tile * RTS + ((it * (RTS * NG) + tid) >> 3);
     const int *lp = lstart + (size_t)n * (npix + 1) + (qq < npix ? qq : npix - 1);
     l0a[it] = lp[0];
     l1a[it] = qq < npix ? lp[1] : 0;                     // pixels past the image merge nothing
+    lab[it] = 0;
+    if (LOSS) {                                          // labels lie as the output does: rows flipped
+      const int qs = qq < npix ? qq : npix - 1;
+      const int rr = (int)(((unsigned)qs * wmagic) >> 24), cc = qs - rr * W;
+      lab[it] = lo.labels[(size_t)n * npix + (unsigned)((W - 1 - rr) * W + cc)];
+    }
   }
   const uint2 *lrecn = lrec + (size_t)n * K;
   const int lbase = goffn[P];
@@ -706,6 +722,10 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   uint2 lr0[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) lr0[it] = lrecn[min(l0a[it] + sub, K - 1)];
+  float wlab[NIT];                                       // LOSS: the labelled class' weight (focal_loss.py:20-41)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    wlab[it] = (LOSS && lo.class_w) ? lo.class_w[min(max(lab[it], 0), 31)] : 1.0f;
   const f32x2 fc2 = {fc, fc}, fr2 = {fr, fr};
   float *myS = &sS[pt * SLD + 1];                        // indexed by part (channel = part + 1)
   short *myA = &sA[pt * ALD + 1];
@@ -839,11 +859,32 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
     }
     const int qq = tile * RTS + pl;
+    float ls = 0.0f, inv = 0.0f, k1 = 0.0f;
+    if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
+      const float den = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
+      const int t = lab[it];
+      const float vt = (t & 2) ? ((t & 1) ? v[3] : v[2]) : ((t & 1) ? v[1] : v[0]);
+      const float st = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);   // the labelled class' score in all 8 lanes (+ exact zeros)
+      inv = 1.0f / den;
+      const float sm = __expf(st) * inv;
+      const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
+      const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
+      const float om = 1.0f - p, lg = logf(p), w = wlab[it];
+      ls = (unsigned)t < 32u ? pow_gamma(om, lo.gamma) * ((-lg) * w) : 0.0f;     // :18, :41, :43-44
+      // d loss / d softmax_t (the clip passes gradient on [eps, 1 - eps] only) x softmax_t: with it
+      // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
+      k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pow_gamma(om, lo.gamma) / p)) * sm : 0.0f;
+    }
     if (qq < npix && c4 < C) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
       const unsigned po = (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68); mesh base + 32-bit offset
+      if (LOSS && c4 == 0) {
+        lo.loss[(size_t)n * npix + po] = ls;
+        lo.stats[(size_t)n * npix + po] = make_float4(a[0] ? inv : -inv, v[0], k1, __int_as_float(lab[it]));
+      }
       float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
-      if (c4 + 3 < C && (C & 3) == 0) {
+      if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
+      } else if (c4 + 3 < C && (C & 3) == 0) {
         *reinterpret_cast<float4 *>(so) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         for (int t = 0; t < 4; ++t)
@@ -1876,21 +1917,29 @@ static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fus
 
 // stage 2: the pair loop + merge + write-out over a binned workspace
 static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const void *workspace, const float *rec,
-                           float *seg, int16_t *arg, void *stream) {
+                           float *seg, int16_t *arg, void *stream, LossOut lo = LossOut{}) {
   SMPLR_REQUIRE(B >= 0 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
                 "%s: bad sizes B=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, W, P, K);
+  const bool with_loss = lo.loss != nullptr;
+  SMPLR_REQUIRE(!with_loss || (P == 31 && lo.gamma >= 0.0f),
+                "%s: the loss epilogue is the 32-class head's (P = 31, gamma >= 0): P=%d gamma=%g", fn, P, (double)lo.gamma);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(workspace && rec && seg && arg, "%s: null pointer", fn);
+  SMPLR_REQUIRE(workspace && rec && (seg || with_loss) && arg, "%s: null pointer", fn);
+  SMPLR_REQUIRE(!with_loss || (lo.labels && lo.stats), "%s: the loss epilogue needs labels and stats", fn);
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
   const char *base = reinterpret_cast<const char *>(workspace);
   const int ntiles = (W * W + RTS - 1) / RTS;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
-  hipLaunchKernelGGL(raster_fwd_kernel, dim3(grid), dim3(RTS * NG), 0, as_stream(stream),
-                     reinterpret_cast<const float4 *>(rec), reinterpret_cast<const int *>(base + ws.goff_off),
-                     reinterpret_cast<const int *>(base + ws.lstart_off),
-                     reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, seg,
-                     reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W));
+#define SMPLR_RASTER_LAUNCH(LOSS_)                                                                             \
+  hipLaunchKernelGGL(raster_fwd_kernel<LOSS_>, dim3(grid), dim3(RTS * NG), 0, as_stream(stream),               \
+                     reinterpret_cast<const float4 *>(rec), reinterpret_cast<const int *>(base + ws.goff_off), \
+                     reinterpret_cast<const int *>(base + ws.lstart_off),                                      \
+                     reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, seg,          \
+                     reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W), lo)
+  if (with_loss) SMPLR_RASTER_LAUNCH(true);
+  else SMPLR_RASTER_LAUNCH(false);
+#undef SMPLR_RASTER_LAUNCH
   SMPLR_LAUNCH_CHECK(fn);
   return 0;
 }

@@ -36,6 +36,25 @@ def test_gpus_2_launches_two_ranks_itself():
     assert abs(elapsed - max(d["rank_elapsed_s"])) < 1e-9
     assert elapsed >= max(d["rank_work_s"]) and d["rank_work_s"][1] > d["rank_work_s"][0]
     assert abs(d["value"] - 12 * 4 / elapsed) < 0.1     # whole-job rate: all ranks' meshes / max time
+    # the train leg's protocol (a CPU stand-in under DDP / gloo here): the step as trained, the same step without the
+    # gradient all-reduce, the all-reduce's volume - the keys the GPU leg prints
+    t = d["train_step"]
+    assert t["stand_in"] and t["ddp"] and t["backend"] == "gloo" and t["n_gpus"] == 2 and t["scaling"] == "weak"
+    assert t["global_batch"] == 2 * t["images_per_gpu"] and t["allreduce_MiB"] > 0
+    for k in ("ddp_step", "no_sync_step"):
+        assert t[k]["ms_per_step"] > 0 and t[k]["images_per_s"] > 0
+    assert abs(t["allreduce_exposed_ms"] - (t["ddp_step"]["ms_per_step"] - t["no_sync_step"]["ms_per_step"])) < 2e-3
+
+
+def test_strong_scaling_splits_a_fixed_global_batch():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--scaling", "strong", "--global-batch", "10", "--dry-run",
+              "--no-train-leg"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.strip()][0])
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 10 and d["config"]["meshes_per_gpu"] == 5
+    assert d["train_step"] is None
+    r = _run(["--gpus", "2", "--scaling", "strong", "--global-batch", "9", "--dry-run"])
+    assert r.returncode != 0 and b"does not split" in r.stderr
 
 
 def test_world_size_mismatch_is_an_error():
@@ -60,7 +79,8 @@ def test_gpus_2_on_a_one_gpu_box():
     """The real N = 2 path on hardware: `bench.py --gpus 2` starts two ranks itself, both on cuda:0 (local rank modulo
     the device count), process group over gloo (RCCL needs a device per rank): HIP graph capture, barrier-bracketed
     timing, MAX over ranks, one line with n_gpus = 2 and the whole-job rate."""
-    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-breakdown"],
+    r = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-breakdown", "--train-batch", "16",
+              "--train-steps", "3", "--train-global-batch", "64"],
              env={"BENCH_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
@@ -69,3 +89,14 @@ def test_gpus_2_on_a_one_gpu_box():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["config"]["meshes_per_gpu"] == 128
     assert d["value"] > 0 and abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
     assert "dry_run" not in d and d["config"]["launch"] in ("graph", "eager")
+    w = d["ms_per_step_windows"]
+    assert w["n"] == 10 and w["min"] <= w["median"] <= w["max"] and w["min"] > 0
+    assert len(d["build_id"]) == 64
+    # the data-parallel train step (BASELINE configs[4]: ENet + IEF + decoder with both heads + both losses + Adam
+    # under DistributedDataParallel): the step as trained, without the all-reduce, and the all-reduce's volume
+    t = d["train_step"]
+    assert t["ddp"] and t["n_gpus"] == 2 and t["images_per_gpu"] == 16 and t["global_batch"] == 32
+    assert 50.0 < t["allreduce_MiB"] < 60.0                          # ENet + IEF: 14.58 M parameters = 55.6 MiB
+    for k in ("ddp_step", "no_sync_step"):
+        assert t[k]["ms_per_step"] > 0 and t[k]["images_per_s"] > 0
+    assert "allreduce_exposed_ms" in t and t["strong_global_64"]["scaling"] == "strong" and t["strong_global_64"]["images_per_gpu"] == 32
