@@ -313,7 +313,7 @@ def parity_sample(model, consts, pt, W, dev, Bp=2):
     from oracle import np_oracle as no
     xs = make_x(Bp, W, 4242)
     x = torch.tensor(xs, device=dev)
-    verts, proj, mask, seg, _silh, _jt = ops.DecoderFn.apply(x, consts, 4, W, 1, pt, 64, True, False, 1)
+    verts, proj, mask, seg, _silh, _jt, _ls = ops.DecoderFn.apply(x, consts, 4, W, 1, pt, 64, True, False, 1)
     ref_v = no.smpl_layer_call(xs.astype(np.float64), model)
     pj = proj.cpu().numpy().astype(np.float64)
     ref_m = no.compute_mask(pj)
@@ -604,7 +604,7 @@ def main():
 
     def step():
         xg = x.detach().requires_grad_(True)
-        verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False,
+        verts, proj, mask, seg, silh, jt, _ls = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False,
                                                                args.streams)
         seg.backward(dseg)
         return xg.grad
@@ -713,7 +713,7 @@ def main():
 
                 def step32():
                     xg = x.detach().requires_grad_(True)
-                    _v, _p, _m, sg_, _s, _j = ops.DecoderFn.apply(xg, c32, 4, W, 1, pt, 64, True, False, 1)
+                    _v, _p, _m, sg_, _s, _j, _l = ops.DecoderFn.apply(xg, c32, 4, W, 1, pt, 64, True, False, 1)
                     sg_.backward(dseg)
                 step32()
                 t32 = graph_time_ms(step32, 5, torch.cuda.current_stream())
@@ -827,7 +827,7 @@ def main():
 
                 def step_silh():
                     xg = x.detach().requires_grad_(True)
-                    _v, _p, _m, sg_, sl_, _j = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, True, 1)
+                    _v, _p, _m, sg_, sl_, _j, _l = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, True, 1)
                     torch.autograd.backward([sg_, sl_], [dseg, dsl])
                 step_silh()
                 t_ds = graph_time_ms(step_silh, 5, torch.cuda.current_stream())
@@ -835,12 +835,65 @@ def main():
                                                           "meshes_per_s": round(B / (t_ds * 1e-3), 1)}
             except Exception as e:
                 line["aux"]["decoder_with_silhouette"] = {"error": str(e)}
+            # decoder + loss head fwd+bwd (the TRAIN path's decoder): unfused = scores written,
+            # smplr_focal_fwd / bwd, dseg read back; fused = the loss head inside the rasteriser (DecoderOpts.loss), the
+            # (B,W,W,32) scores and their gradient never in memory; seg_only = the default step without verts / proj / mask
+            try:
+                from ilps_amd.focal_loss import class_weights
+                labs = torch.randint(0, 32, (B, W, W), device=dev, dtype=torch.int32)
+                cwt = class_weights(dev)
+                dlp = torch.full((B, W * W), 1.0 / (B * W * W), device=dev)
+
+                def step_unfused():
+                    xg = x.detach().requires_grad_(True)
+                    o_ = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1)
+                    ops.SoftmaxFocalFn.apply(o_[3], labs, cwt, 2.0).backward(dlp)
+
+                def mk_fused(**kw):
+                    op_ = ops.DecoderOpts(loss=(labs, cwt, 2.0), want_seg=False, **kw)
+
+                    def f():
+                        xg = x.detach().requires_grad_(True)
+                        ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1, False, op_)[6].backward(dlp)
+                    return f
+                step_fused_all = mk_fused()
+                step_fused = mk_fused(want_verts=False, want_proj=False, want_mask=False)
+                op_so = ops.DecoderOpts(want_verts=False, want_proj=False, want_mask=False)
+
+                def step_seg_only():
+                    xg = x.detach().requires_grad_(True)
+                    ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1, False, op_so)[3].backward(dseg)
+                ent = {}
+                for nm, fn in (("unfused", step_unfused), ("fused", step_fused), ("fused_all_outputs", step_fused_all),
+                               ("seg_only_no_loss", step_seg_only)):
+                    fn()
+                    tms = graph_time_ms(fn, 5, torch.cuda.current_stream())
+                    ent[nm] = {"ms_per_step": round(tms, 4), "meshes_per_s": round(B / (tms * 1e-3), 1)}
+                ent["note"] = ("decoder + softmax-focal loss fwd+bwd; fused = loss head as the rasteriser's epilogue / "
+                               "seg_bwd's prologue, no verts / proj / mask / seg written; seg_only_no_loss = the headline "
+                               "step without verts / proj / mask")
+                line["aux"]["decoder_plus_loss"] = ent
+            except Exception as e:
+                line["aux"]["decoder_plus_loss"] = {"error": str(e)}
+            # the silhouette-only pass of the alternating stage-2 schedule (train_stage2_silhouette.py:262-270)
+            try:
+                op_s = ops.DecoderOpts(want_verts=False, want_mask=False, seg=False)
+                dsl2 = torch.randn(B, W, W, 2, device=dev)
+
+                def step_silh_only():
+                    xg = x.detach().requires_grad_(True)
+                    ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, True, 1, False, op_s)[4].backward(dsl2)
+                step_silh_only()
+                t_so = graph_time_ms(step_silh_only, 5, torch.cuda.current_stream())
+                line["aux"]["silhouette_only_step"] = {"ms_per_step": round(t_so, 4), "meshes_per_s": round(B / (t_so * 1e-3), 1)}
+            except Exception as e:
+                line["aux"]["silhouette_only_step"] = {"error": str(e)}
             # the same step with the bit-reproducible backward (SMPLDecoder(deterministic=True): 64-bit fixed-point
             # accumulation in seg_bwd instead of fp32 LDS atomics) - its price
             try:
                 def step_det():
                     xg = x.detach().requires_grad_(True)
-                    _v, _p, _m, sg_, _s, _j = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1, True)
+                    _v, _p, _m, sg_, _s, _j, _l = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1, True)
                     sg_.backward(dseg)
                 step_det()
                 t_dd = graph_time_ms(step_det, 5, torch.cuda.current_stream())

@@ -258,6 +258,36 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
                   int B, int VP, int W, int P, int K, float *dproj, void *workspace, int deterministic,
                   void *stream);
 
+/* ---- projects_to_seg + the loss head in one pass: keras_smpl/projects_to_seg.py:34-69 + model.py:119-120 +
+ * focal_loss.py:10-46 ("fuses the seg tensor's last read into the loss") -----------------
+ * The rasteriser's write-out phase holds a pixel's 32 raw scores in 8 adjacent lanes, so Reshape + softmax + the
+ * focal loss at an INTEGER class map are its epilogue: labels (B, W, W) int32 as the output lies (rows flipped; an id
+ * outside [0, 32) contributes no loss and no gradient, as in smplr_focal_fwd), class_w (32) or NULL, gamma >= 0
+ * -> loss (B, W*W) per pixel (the value smplr_focal_fwd would return on the scores) and stats (B, W*W, 4) fp32 for
+ * the backward: [+-1 / sum_c exp(score_c), sign = the background clip's gate | background score | q_t softmax_t |
+ * label bits].  seg may be NULL: the (B, W, W, 32) scores then never leave the chip (295 KB per mesh not written,
+ * and not read twice by the loss kernels); arg and rec are written as by smplr_seg_fwd.  P must be 31.
+ *   smplr_seg_raster_loss        = smplr_seg_raster with the epilogue (after smplr_seg_bin)
+ *   smplr_skin_vis_seg_loss_fwd  = smplr_skin_vis_seg_fwd with the epilogue (what the decoder runs when it is given a
+ *                                  loss); verts, proj, mask, seg may each be NULL
+ *   smplr_seg_loss_bwd           = smplr_seg_bwd fed with dloss (B, W*W) and stats instead of dseg: a lane rebuilds its
+ *                                  channel's d loss / d score = A (delta_ct - softmax_c) - g_background from its own
+ *                                  recomputed score, A = dloss q_t softmax_t (20 B per pixel read instead of 128);
+ *                                  same workspace, dproj = NULL and deterministic as smplr_seg_bwd.
+ * The softmax takes no max shift (scores lie in [0, 1]) and uses v_exp_f32; against smplr_focal_fwd/bwd on the written
+ * scores the loss agrees to ~1e-6 relative (tests/test_gpu_loss_fused.py).                                       */
+int smplr_seg_raster_loss(int B, int W, int P, int K, const void *workspace, const float *rec,
+                          const int32_t *labels, const float *class_w, float gamma, float *seg, int16_t *arg,
+                          float *loss, float *stats, void *stream);
+int smplr_skin_vis_seg_loss_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
+                                int x_stride, int B, int V, int W, int grid_wh, int ref_compat,
+                                const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,
+                                const int32_t *labels, const float *class_w, float gamma, float *verts, float *proj,
+                                float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, float *loss,
+                                float *stats, void *stream);
+int smplr_seg_loss_bwd(const float *dloss, const float *stats, const int16_t *arg, const float *rec, int B, int VP,
+                       int W, int P, int K, float *dproj, void *workspace, int deterministic, void *stream);
+
 /* ---- projects_to_silhouette: keras_smpl/projects_to_silhouette.py:14-44 ----------------- */
 /* silh (B,W,W,2) = [1-s, s], s = max_v exp(-|proj_v-(c,r)|/1.2) over ALL VP vertices, rows
  * flipped; arg (B,W,W) int32 = maximising vertex.  workspace: smplr_silh_workspace(B,VP,W) B.  */

@@ -1042,12 +1042,119 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
   else seg_flush(acc, cur, sx, sy);
 }
 
-template <bool DET>
+// The row walk when the loss head's backward is fused in (seg_bwd_kernel<.., LOSS = true>): d loss / d score of a
+// channel is rebuilt per pixel from what the forward's loss epilogue left (raster_fwd_kernel<true>),
+//   g_c = A (delta_ct - softmax_c) - g_background,   A = dloss q_t softmax_t,   softmax_c = exp(score_c) / sum exp,
+// with score_c the lane's own recomputed score: every lane of a pixel's 32-lane group reads the same 16 B of `stats`
+// (+- 1 / sum exp with the clip's gate as its sign | background score | q_t softmax_t | label) and 4 B of dloss - one
+// request per group - instead of its own 4 B of a 128-B row of dseg, and folds them at once into the two numbers it
+// needs per pixel, c1 = A delta_ct - g_background and c2 = A / sum exp (g_c = c1 - c2 exp(score_c)).
+struct LossIn { const float *dloss; const float4 *stats; };
+
+// one batch of SB_U pixels of a row: a = arg-min slots, dl = dloss, st = stats of the pixels c0 .. c0 + SB_U - 1
+template <bool MW, bool DET>
+__device__ __forceinline__ void seg_bwd_batch_loss(int c0, int (&a)[SB_U], const float (&dl)[SB_U],
+                                                   const float4 (&st)[SB_U], __amdgpu_buffer_rsrc_t rrs, float *acc,
+                                                   int W, bool chok, int ch, float fr, int base, float scale, int &cur,
+                                                   float &sx, float &sy) {
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+  float c1[SB_U], c2[SB_U];
+  float4 rv[SB_U];
+#pragma unroll
+  for (int u = 0; u < SB_U; ++u) {
+    const float A = dl[u] * st[u].z, inv = fabsf(st[u].x);
+    // what every channel subtracts: the background's gradient A (delta_0t - softmax_0) where the clip's gate is open
+    const float gb0 = A * ((__float_as_int(st[u].w) == 0 ? 1.0f : 0.0f) - __expf(st[u].y) * inv);
+    c1[u] = (__float_as_int(st[u].w) == ch ? A : 0.0f) - (st[u].x > 0.0f ? gb0 : 0.0f);
+    c2[u] = A * inv;
+    if (!(chok && c0 + u < W)) a[u] = -1;
+    if (MW) {
+      a[u] -= base;
+      if (a[u] >= SB_SLOTS) a[u] = -1;
+    }
+    rv[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, (base + a[u]) * 16, 0, 0));
+  }
+#pragma unroll
+  for (int u = 0; u < SB_U; ++u) {
+    const float fc = (float)(c0 + u);
+    const float du = rv[u].x - fc, dv = rv[u].y - fr;
+    const float d2 = fmaf(du, du, dv * dv);
+    const float t = d2 * rv[u].z;
+    const float r = __builtin_amdgcn_rsqf(fmaxf(t, 1e-37f));      // (see seg_bwd_row: m d = t r, m / d = m^2 r)
+    const float sc = fast_exp_neg(t * r);
+    const float g = c1[u] - c2[u] * __expf(sc);
+    float kk = (-g * sc) * (rv[u].z * r);                          // (a masked slot read zeros: m^2 = 0, kk = 0)
+    if (MW && a[u] < 0) kk = 0.0f;
+    const bool on = kk != 0.0f;
+    if (on && a[u] != cur) {
+      if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+      else seg_flush(acc, cur, sx, sy);
+      cur = a[u];
+      sx = 0.0f;
+      sy = 0.0f;
+    }
+    sx = fmaf(kk, du, sx);
+    sy = fmaf(kk, dv, sy);
+  }
+}
+
+// pa / pg: the first batch's arg-min slots and dloss as requested at kernel entry (FAST); its stats were only touched
+// there (one dword per lane = the batch's 128 B: an L1 hit now) - held in registers through the barrier the 32 dwords
+// per lane push the kernel past its register budget and the compiler parks them in scratch, behind a wait for the
+// very requests they were to overlap.
+template <bool MW, bool FAST, bool DET>
+__device__ __forceinline__ void seg_bwd_row_loss(LossIn li, const short *__restrict__ arg, const float4 *__restrict__ R,
+                                                 int rbytes, float *acc, size_t row0, int W, int C, int ch, float fr,
+                                                 int base, float scale, const int *pa, const float *pg) {
+  const bool chok = ch >= 1 && ch < C;
+  const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(R), 0, rbytes, 0x00020000);
+  const short *arow = arg + row0 * 32 + ch;
+  const float *drow = li.dloss + row0;
+  const float4 *srow = li.stats + row0;
+  int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
+  float sx = 0.0f, sy = 0.0f;
+  for (int c0 = 0; c0 < W; c0 += SB_U) {
+    int a[SB_U];
+    float dl[SB_U];
+    float4 st[SB_U];
+    if (FAST) {                                    // W a multiple of SB_U: one address per stream, immediate offsets
+      const short *ab = arow + c0 * 32;
+      const float *db = drow + c0;
+      const float4 *sb = srow + c0;
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) {
+        if (c0 == 0) {                             // (uniform)
+          a[u] = pa[u];
+          dl[u] = pg[u];
+        } else {
+          a[u] = ab[u * 32];
+          dl[u] = db[u];
+        }
+        st[u] = sb[u];
+      }
+    } else {                                       // (pixels past the row's end repeat its last one and are masked)
+#pragma unroll
+      for (int u = 0; u < SB_U; ++u) {
+        const int cc = min(c0 + u, W - 1);
+        a[u] = arow[cc * 32];
+        dl[u] = drow[cc];
+        st[u] = srow[cc];
+      }
+    }
+    seg_bwd_batch_loss<MW, DET>(c0, a, dl, st, rrs, acc, W, chok, ch, fr, base, scale, cur, sx, sy);
+  }
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+  if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+  else seg_flush(acc, cur, sx, sy);
+}
+
+template <bool DET, bool LOSS>
 __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *__restrict__ dseg,
                                                       const short *__restrict__ arg,
                                                       const float4 *__restrict__ rec, int S, int VP, int W,
                                                       int P, float *__restrict__ dproj,
-                                                      float *__restrict__ part, int rows) {
+                                                      float *__restrict__ part, int rows, LossIn li) {
   // SB_SLOTS x 2 accumulators: fp32 (32 KB), or 64-bit fixed point in the deterministic form (64 KB)
   extern __shared__ __attribute__((aligned(16))) float acc[];
   unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
@@ -1070,14 +1177,16 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
   // 20 us kernel that otherwise streams at 4.8 TB/s) then runs under the zeroing of the accumulators and its barrier.
   int pa[SB_U];
   float pg[SB_U];
+  float warm = 0.0f;                                          // LOSS: touches the first batch's stats (see seg_bwd_row_loss)
 #pragma unroll
   for (int u = 0; u < SB_U; ++u) { pa[u] = 0; pg[u] = 0.0f; }
   if (fast && ro < W) {
 #pragma unroll
     for (int u = 0; u < SB_U; ++u) {
       pa[u] = arg[(row0 + u) * 32 + ch];
-      pg[u] = dseg[(row0 + u) * 32 + ch];
+      pg[u] = LOSS ? li.dloss[row0 + u] : dseg[(row0 + u) * 32 + ch];
     }
+    if (LOSS) warm = reinterpret_cast<const float *>(li.stats + row0)[ch];
   }
   if (dproj) {                                                // (NULL: the consumer gathers the slot sums itself)
     // this block's share of the mesh's dproj rows := 0 (the merge kernel then stores the sums)
@@ -1094,8 +1203,12 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     if (tid == 0) { s_gmax = 0u; s_m2max = 0u; }
     __syncthreads();
     unsigned gm = 0u, mm = 0u;
-    if (ro < W)
-      for (int i = ch; i < W * C; i += 32) gm = max(gm, __float_as_uint(fabsf(dseg[row0 * C + i])));
+    if (ro < W) {
+      if (LOSS)        // |g_c| = |A (delta_ct - softmax_c) - g_background| <= 2 |A|, A = dloss q_t softmax_t
+        for (int i = ch; i < W; i += 32) gm = max(gm, __float_as_uint(fabsf(2.0f * li.dloss[row0 + i] * li.stats[row0 + i].z)));
+      else
+        for (int i = ch; i < W * C; i += 32) gm = max(gm, __float_as_uint(fabsf(dseg[row0 * C + i])));
+    }
     for (int i = tid; i < nslots; i += nthr) mm = max(mm, __float_as_uint(fabsf(R[i].z)));
     atomicMax(&s_gmax, gm);
     atomicMax(&s_m2max, mm);
@@ -1124,7 +1237,15 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
       // (the compiler would otherwise start on the first batch - and wait for it - in front of the barrier)
 #pragma unroll
       for (int u = 0; u < SB_U; ++u) asm volatile("" : "+v"(pa[u]), "+v"(pg[u]));
-      if (nwin == 1 && fast)
+      if (LOSS) {
+        asm volatile("" : "+v"(warm));
+        if (nwin == 1 && fast)
+          seg_bwd_row_loss<false, true, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
+        else if (nwin == 1)
+          seg_bwd_row_loss<false, false, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
+        else
+          seg_bwd_row_loss<true, false, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale, pa, pg);
+      } else if (nwin == 1 && fast)
         seg_bwd_row<false, true, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
       else if (nwin == 1)
         seg_bwd_row<false, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
@@ -2000,6 +2121,29 @@ int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const fl
   return seg_raster_impl("smplr_skin_vis_seg_fwd", B, W, P, K, workspace, rec, seg, arg, stream);
 }
 
+int smplr_seg_raster_loss(int B, int W, int P, int K, const void *workspace, const float *rec, const int32_t *labels,
+                          const float *class_w, float gamma, float *seg, int16_t *arg, float *loss, float *stats,
+                          void *stream) {
+  SMPLR_REQUIRE(B <= 0 || loss, "smplr_seg_raster_loss: null loss");
+  return smplr::seg_raster_impl("smplr_seg_raster_loss", B, W, P, K, workspace, rec, seg, arg, stream,
+                                smplr::LossOut{labels, class_w, gamma, loss, reinterpret_cast<float4 *>(stats)});
+}
+
+int smplr_skin_vis_seg_loss_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
+                                int x_stride, int B, int V, int W, int grid_wh, int ref_compat, const int32_t *part_pos,
+                                const int32_t *part_off, int P, int K, void *workspace, const int32_t *labels,
+                                const float *class_w, float gamma, float *verts, float *proj, float *mask, float *seg,
+                                int16_t *arg, float *rec, int16_t *vslot, float *loss, float *stats, void *stream) {
+  using namespace smplr;
+  SMPLR_REQUIRE(B <= 0 || (v_posed && lbs_top4 && A && cam && loss), "smplr_skin_vis_seg_loss_fwd: null pointer");
+  const SkinIn sk{v_posed, lbs_top4, A, cam, x_stride, verts, proj};
+  int rc = seg_bin_impl("smplr_skin_vis_seg_loss_fwd", proj, mask, true, grid_wh, ref_compat, B, V, W, part_pos, part_off,
+                        P, K, workspace, rec, vslot, stream, sk);
+  if (rc) return rc;
+  return seg_raster_impl("smplr_skin_vis_seg_loss_fwd", B, W, P, K, workspace, rec, seg, arg, stream,
+                         LossOut{labels, class_w, gamma, loss, reinterpret_cast<float4 *>(stats)});
+}
+
 int smplr_seg_bwd_nsplit(int B, int W) {
   if (B <= 0 || W <= 0) return 0;
   const int rows = smplr::seg_bwd_rows(B, W);
@@ -2012,36 +2156,57 @@ size_t smplr_seg_bwd_workspace(int B, int W) {
   return (size_t)B * nsplit * smplr::SB_NWIN * smplr::SB_SLOTS * 2 * sizeof(float);
 }
 
-int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B, int VP, int W, int P, int K,
-                  float *dproj, void *workspace, int deterministic, void *stream) {
-  using namespace smplr;
+namespace smplr {
+static int seg_bwd_impl(const char *fn, const float *dseg, LossIn li, const int16_t *arg, const float *rec, int B, int VP,
+                        int W, int P, int K, float *dproj, void *workspace, int deterministic, void *stream) {
   SMPLR_REQUIRE(B >= 0 && VP > 0 && VP <= 32767 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= 16000,
-                "smplr_seg_bwd: bad sizes B=%d VP=%d W=%d P=%d K=%d", B, VP, W, P, K);
+                "%s: bad sizes B=%d VP=%d W=%d P=%d K=%d", fn, B, VP, W, P, K);
+  const bool with_loss = li.dloss != nullptr;
+  SMPLR_REQUIRE(!with_loss || P == 31, "%s: the loss head has 32 classes (P = 31), not P=%d", fn, P);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(dseg && arg && rec && workspace, "smplr_seg_bwd: null pointer");
+  SMPLR_REQUIRE((with_loss ? li.stats != nullptr : dseg != nullptr) && arg && rec && workspace, "%s: null pointer", fn);
   hipStream_t st = as_stream(stream);
   const int rows = seg_bwd_rows(B, W), nsplit = (W + rows - 1) / rows;
   const int S = seg_slots(P, K);
-  SMPLR_REQUIRE(S <= SB_NWIN * SB_SLOTS, "smplr_seg_bwd: %d record slots exceed %d", S, SB_NWIN * SB_SLOTS);
+  SMPLR_REQUIRE(S <= SB_NWIN * SB_SLOTS, "%s: %d record slots exceed %d", fn, S, SB_NWIN * SB_SLOTS);
+#define SMPLR_SEGBWD_LAUNCH(DET_, LOSS_, lds_)                                                                       \
+  hipLaunchKernelGGL((seg_bwd_kernel<DET_, LOSS_>), dim3(nsplit, B), dim3(32 * rows), lds_, st, dseg,                 \
+                     reinterpret_cast<const short *>(arg), reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, \
+                     reinterpret_cast<float *>(workspace), rows, li)
   if (deterministic) {
     const size_t lds = (size_t)SB_SLOTS * 2 * sizeof(unsigned long long);
-    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true>), lds);
+    int rc = with_loss ? set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true, true>), lds)
+                       : set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true, false>), lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(seg_bwd_kernel<true>, dim3(nsplit, B), dim3(32 * rows), lds, st, dseg,
-                       reinterpret_cast<const short *>(arg), reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj,
-                       reinterpret_cast<float *>(workspace), rows);
+    if (with_loss) SMPLR_SEGBWD_LAUNCH(true, true, lds);
+    else SMPLR_SEGBWD_LAUNCH(true, false, lds);
   } else {
-    hipLaunchKernelGGL(seg_bwd_kernel<false>, dim3(nsplit, B), dim3(32 * rows), (size_t)SB_SLOTS * 2 * sizeof(float), st,
-                       dseg, reinterpret_cast<const short *>(arg), reinterpret_cast<const float4 *>(rec), S, VP, W, P,
-                       dproj, reinterpret_cast<float *>(workspace), rows);
+    const size_t lds = (size_t)SB_SLOTS * 2 * sizeof(float);
+    if (with_loss) SMPLR_SEGBWD_LAUNCH(false, true, lds);
+    else SMPLR_SEGBWD_LAUNCH(false, false, lds);
   }
-  SMPLR_LAUNCH_CHECK("smplr_seg_bwd");
+#undef SMPLR_SEGBWD_LAUNCH
+  SMPLR_LAUNCH_CHECK(fn);
   if (!dproj) return 0;                        // slot sums only: smplr_smpl_bwd gathers them by vertex
   hipLaunchKernelGGL(seg_bwd_merge_kernel, dim3(SB_SLOTS / 256, B), dim3(256), 0, st,
                      reinterpret_cast<const float *>(workspace), reinterpret_cast<const float4 *>(rec), S, VP, nsplit,
                      dproj);
-  SMPLR_LAUNCH_CHECK("smplr_seg_bwd(merge)");
+  SMPLR_LAUNCH_CHECK(fn);
   return 0;
+}
+}  // namespace smplr
+
+int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec, int B, int VP, int W, int P, int K,
+                  float *dproj, void *workspace, int deterministic, void *stream) {
+  return smplr::seg_bwd_impl("smplr_seg_bwd", dseg, smplr::LossIn{nullptr, nullptr}, arg, rec, B, VP, W, P, K, dproj,
+                             workspace, deterministic, stream);
+}
+
+int smplr_seg_loss_bwd(const float *dloss, const float *stats, const int16_t *arg, const float *rec, int B, int VP, int W,
+                       int P, int K, float *dproj, void *workspace, int deterministic, void *stream) {
+  SMPLR_REQUIRE(B <= 0 || dloss, "smplr_seg_loss_bwd: null dloss");
+  return smplr::seg_bwd_impl("smplr_seg_loss_bwd", nullptr, smplr::LossIn{dloss, reinterpret_cast<const float4 *>(stats)},
+                             arg, rec, B, VP, W, P, K, dproj, workspace, deterministic, stream);
 }
 
 size_t smplr_silh_workspace(int B, int VP, int W) {

@@ -355,6 +355,57 @@ def _skin_vis_seg_fwd(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, grid_
 
 
 @on_device
+def _skin_vis_seg_loss_fwd(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, labels, class_w, gamma, grid_wh=64,
+                           ref_compat=True, verts=None, proj=None, mask=None, seg=None, arg=None, rec=None, vslot=None,
+                           loss=None, stats=None):
+    """_skin_vis_seg_fwd with the loss head as the rasteriser's epilogue (smplr_skin_vis_seg_loss_fwd): labels (B,W,W)
+    int32 -> loss (B, W*W), stats (B, W*W, 4); verts / proj / mask / seg are written only where a tensor is given."""
+    lib = _lib.load()
+    B, V = v_posed.shape[0], c.V
+    if c.lbs_top4 is None or pt.VP != V or not lib.smplr_skin_vis_seg_fits(V, int(W), int(grid_wh)):
+        raise RuntimeError("_skin_vis_seg_loss_fwd: needs sparse skinning weights, vertex_sampling = 1 and sizes that fit "
+                           "the binning workgroup's LDS (smplr_skin_vis_seg_fits)")
+    ws = _workspace(lib.smplr_seg_workspace(B, V, W, pt.P, pt.K), v_posed)
+    if arg is None:
+        arg = _empty((B, W, W, 32), v_posed, torch.int16)
+    if rec is None:
+        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), v_posed)
+    loss = _empty((B, W * W), v_posed) if loss is None else loss
+    stats = _empty((B, W * W, 4), v_posed) if stats is None else stats
+    check(lib.smplr_skin_vis_seg_loss_fwd(ptr(v_posed), ptr(c.lbs_top4), ptr(A), ptr(cam), cam.shape[1], B, V, W,
+                                          int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos), ptr(pt.part_off),
+                                          pt.P, pt.K, ptr(ws), ptr(labels), ptr(class_w), float(gamma), ptr(verts),
+                                          ptr(proj), ptr(mask), ptr(seg), ptr(arg), ptr(rec), ptr(vslot), ptr(loss),
+                                          ptr(stats), stream()), "smplr_skin_vis_seg_loss_fwd")
+    return loss, stats, arg, rec
+
+
+@on_device
+def _seg_raster_loss(ws, rec, B, W, pt: PartTable, labels, class_w, gamma, seg=None, arg=None, loss=None, stats=None):
+    """Stage 2 with the loss epilogue (smplr_seg_raster_loss) over a binned workspace -> loss, stats, arg."""
+    lib = _lib.load()
+    if arg is None:
+        arg = _empty((B, W, W, 32), rec, torch.int16)
+    loss = _empty((B, W * W), rec) if loss is None else loss
+    stats = _empty((B, W * W, 4), rec) if stats is None else stats
+    check(lib.smplr_seg_raster_loss(B, W, pt.P, pt.K, ptr(ws), ptr(rec), ptr(labels), ptr(class_w), float(gamma),
+                                    ptr(seg), ptr(arg), ptr(loss), ptr(stats), stream()), "smplr_seg_raster_loss")
+    return loss, stats, arg
+
+
+@on_device
+def _seg_loss_bwd(dloss, stats, arg, rec, VP, W, pt: PartTable, merge=True, deterministic=False):
+    """_seg_bwd fed with dloss (B, W*W) + the forward's stats instead of dseg (smplr_seg_loss_bwd)."""
+    lib = _lib.load()
+    B = arg.shape[0]
+    ws = _workspace(lib.smplr_seg_bwd_workspace(B, W), dloss)
+    dproj = _empty((B, VP, 3), dloss) if merge else None
+    check(lib.smplr_seg_loss_bwd(ptr(dloss), ptr(stats), ptr(arg), ptr(rec), B, VP, W, pt.P, pt.K, ptr(dproj), ptr(ws),
+                                 1 if deterministic else 0, stream()), "smplr_seg_loss_bwd")
+    return dproj if merge else (ws, int(lib.smplr_seg_bwd_nsplit(B, W)))
+
+
+@on_device
 def _seg_bin(proj, mask, W, pt: PartTable, grid_wh=0, ref_compat=True, rec=None, vslot=None, ws=None):
     """Stage 1 of the segmentation forward alone (smplr_seg_bin): grid_wh > 0 computes the mask inside (output),
     grid_wh = 0 reads it.  -> (ws, rec): what _seg_raster needs."""
@@ -799,12 +850,30 @@ def _run_chunks(bounds, device, fn):
         cur.wait_stream(st)
 
 
+@dataclass
+class DecoderOpts:
+    """What a decoder pass computes and writes out (DecoderFn).  Defaults = everything the reference's four model
+    handles expose (model.py:124-153): verts, projects, mask and the 31-part scores."""
+    want_verts: bool = True      # write verts (B,V,3) out; the backward needs none of verts / projects / mask
+    want_proj: bool = True       # (forced on with a silhouette head: the silhouette rasteriser reads it)
+    want_mask: bool = True
+    seg: bool = True             # the 31-part head (compute_mask + projects_to_seg); False: silhouette-only pass
+    want_seg: bool = True        # with `loss`: also write the (B,W,W,32) scores (not differentiable then)
+    # the loss head fused into the rasteriser (model.py:119-120 + focal_loss.py:10-46 at an integer class map):
+    # (labels (B,W,W) integer, class_w (32,) or None, gamma) -> the pass returns the per-pixel loss (B, W*W)
+    loss: Optional[tuple] = None
+
+
 class DecoderFn(torch.autograd.Function):
     """The model.py:108-118 chain as ONE autograd node.
 
-    x (B, 86) -> verts (B,V,3), proj (B,V',3), mask (B,V'), seg (B,W,W,32) [, silh (B,W,W,2)].
+    x (B, 86) -> verts (B,V,3), proj (B,V',3), mask (B,V'), seg (B,W,W,32), silh (B,W,W,2), J_transformed, loss (B,W*W)
+    (outputs that were not asked for - DecoderOpts - come back as empty tensors).
     The projection is the skinning kernel's epilogue, the mask is computed in between, and the
-    backward fuses d(seg)/d(silh)/d(verts)/d(proj) into one skinning-backward launch.
+    backward fuses d(seg)/d(silh)/d(verts)/d(proj) into one skinning-backward launch.  With `opts.loss` the loss
+    head runs as the rasteriser's epilogue and its backward inside the rasteriser's backward: the (B,W,W,32) scores
+    and their gradient never exist in memory.  With `opts.seg = False` only the silhouette head is rendered (the
+    reference's alternating stage-2 schedule, train_stage2_silhouette.py:262-270).
 
     Every op is independent per mesh, so the batch may be cut into `nchunk` contiguous chunks
     whose kernel sequences run concurrently on separate HIP streams: at B = 128 most kernels are
@@ -815,48 +884,94 @@ class DecoderFn(torch.autograd.Function):
     @staticmethod
     @on_device
     def forward(ctx, x, consts: SMPLConstants, num_cam, img_wh, vertex_sampling, pt: PartTable,
-                grid_wh, ref_compat, with_silh, nchunk=1, deterministic=False):
+                grid_wh, ref_compat, with_silh, nchunk=1, deterministic=False, opts: Optional[DecoderOpts] = None):
         x = require_cuda(x, "x")
         ctx.set_materialize_grads(False)
         lib = _lib.load()
+        opts = opts if opts is not None else DecoderOpts()
         vs, W, B = int(vertex_sampling), int(img_wh), x.shape[0]
         # with_silh: False = no silhouette; True = at img_wh; an int = its own resolution
         # (train_stage2_silhouette.py:72-86 renders the silhouettes at `silhs_output_wh`)
         Ws = 0 if not with_silh else (W if with_silh is True else int(with_silh))
+        if not opts.seg and not with_silh:
+            raise RuntimeError("DecoderFn: no head asked for (opts.seg = False needs a silhouette)")
         V, VP = consts.V, (consts.V + vs - 1) // vs
+        dev = x.device
+        none = lambda: torch.empty(0, device=dev)
         Rs, J = _empty((B, 24, 9), x), _empty((B, 24, 3), x)
         A, Jt = _empty((B, 24, 12), x), _empty((B, 24, 3), x)
-        v_posed, verts, proj = _empty((B, V, 3), x), _empty((B, V, 3), x), _empty((B, VP, 3), x)
-        mask = _empty((B, VP), x)
-        seg, arg = _empty((B, W, W, pt.P + 1), x), _empty((B, W, W, 32), x, torch.int16)
-        rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), x)
-        vslot = _empty((B, VP), x, torch.int16)
+        v_posed = _empty((B, V, 3), x)
+        want_proj = opts.want_proj or bool(with_silh)
+        verts = _empty((B, V, 3), x) if opts.want_verts else None
+        proj = _empty((B, VP, 3), x) if want_proj else None
+        mask = _empty((B, VP), x) if (opts.want_mask and opts.seg) else None
+        loss_spec = opts.loss if opts.seg else None
+        labels = class_w = None
+        gamma = 0.0
+        if loss_spec is not None:
+            labels, class_w, gamma = loss_spec
+            if pt.P != 31:
+                raise RuntimeError("the fused loss head is the 32-class one (P = 31)")
+            if labels.numel() != B * W * W or labels.dtype not in (torch.int64, torch.int32, torch.int16, torch.uint8):
+                raise RuntimeError("fused loss: labels must be an integer class map of %d x %d x %d entries" % (B, W, W))
+            labels = require_cuda(labels.to(torch.int32).reshape(B, W, W), "labels", torch.int32)
+            if class_w is not None:
+                class_w = require_cuda(class_w, "class_w")
+                if class_w.numel() != 32:
+                    raise RuntimeError("class_w needs 32 entries")
+        want_seg = opts.seg and (opts.want_seg or loss_spec is None)
+        seg = _empty((B, W, W, pt.P + 1), x) if want_seg else None
+        if opts.seg:
+            arg = _empty((B, W, W, 32), x, torch.int16)
+            rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), x)
+            vslot = _empty((B, VP), x, torch.int16)
+        else:
+            arg = rec = vslot = None
+        loss = _empty((B, W * W), x) if loss_spec is not None else None
+        stats = _empty((B, W * W, 4), x) if loss_spec is not None else None
         if with_silh:
             silh, sarg = _empty((B, Ws, Ws, 2), x), _empty((B, Ws, Ws), x, torch.int32)
         else:
-            silh = sarg = torch.empty(0, device=x.device)
+            silh = sarg = None
 
         # the binning workgroups skin their own vertices (one launch less) when the skinning rows are sparse, every
-        # vertex is rasterised and a mesh fits one trip of the binning kernel; SMPLR_FUSE_SKIN=0 keeps the two calls
-        fuse_skin = (consts.lbs_top4 is not None and vs == 1 and bool(lib.smplr_skin_vis_seg_fits(V, W, int(grid_wh)))
+        # vertex is rasterised and the mesh fits the binning workgroup's LDS; SMPLR_FUSE_SKIN=0 keeps the two calls
+        fuse_skin = (opts.seg and consts.lbs_top4 is not None and vs == 1
+                     and bool(lib.smplr_skin_vis_seg_fits(V, W, int(grid_wh)))
                      and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
+        sl = lambda t, lo, hi: None if t is None else t[lo:hi]
 
         def run(lo, hi):
             xs = x[lo:hi]
+            n = hi - lo
             if consts.blend3_fwd is not None:
                 _pose_blend_fwd(xs, num_cam, consts, out=(Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]), v_posed=v_posed[lo:hi])
             else:
                 coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
-                _blend_fwd(coef, consts, hi - lo, out=v_posed[lo:hi])
-            if fuse_skin:
-                _skin_vis_seg_fwd(v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, grid_wh, ref_compat,
-                                  out=(verts[lo:hi], proj[lo:hi], mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]),
-                                  vslot=vslot[lo:hi])
+                _blend_fwd(coef, consts, n, out=v_posed[lo:hi])
+            if fuse_skin and loss_spec is not None:
+                _skin_vis_seg_loss_fwd(
+                    v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, labels[lo:hi], class_w, gamma, grid_wh, ref_compat,
+                    verts=sl(verts, lo, hi), proj=sl(proj, lo, hi), mask=sl(mask, lo, hi), seg=sl(seg, lo, hi),
+                    arg=arg[lo:hi], rec=rec[lo:hi], vslot=vslot[lo:hi], loss=loss[lo:hi], stats=stats[lo:hi])
+            elif fuse_skin:
+                _skin_vis_seg_opt(v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, grid_wh, ref_compat,
+                                  sl(verts, lo, hi), sl(proj, lo, hi), sl(mask, lo, hi), seg[lo:hi], arg[lo:hi],
+                                  rec[lo:hi], vslot[lo:hi])
             else:
-                _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs,
-                          out=(verts[lo:hi], proj[lo:hi]))
-                _vis_seg_fwd(proj[lo:hi], W, pt, grid_wh, ref_compat,
-                             out=(mask[lo:hi], seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
+                # the two-call path needs proj (and the mask) in memory whatever the caller wants back
+                pj = proj[lo:hi] if proj is not None else _empty((n, VP, 3), x)
+                _skin_fwd(v_posed[lo:hi], A[lo:hi], consts, cam=xs, vertex_sampling=vs, want_verts=verts is not None,
+                          out=(sl(verts, lo, hi), pj))
+                if opts.seg:
+                    mk = mask[lo:hi] if mask is not None else _empty((n, VP), x)
+                    if loss_spec is not None:
+                        ws_, _ = _seg_bin(pj, mk, W, pt, grid_wh, ref_compat, rec=rec[lo:hi], vslot=vslot[lo:hi])
+                        _seg_raster_loss(ws_, rec[lo:hi], n, W, pt, labels[lo:hi], class_w, gamma, seg=sl(seg, lo, hi),
+                                         arg=arg[lo:hi], loss=loss[lo:hi], stats=stats[lo:hi])
+                    else:
+                        _vis_seg_fwd(pj, W, pt, grid_wh, ref_compat,
+                                     out=(mk, seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
             if with_silh:
                 _silh_fwd(proj[lo:hi], Ws, out=(silh[lo:hi], sarg[lo:hi]))
 
@@ -864,23 +979,32 @@ class DecoderFn(torch.autograd.Function):
         if B > 0:
             _run_chunks(bounds, x.device, run)
         ctx.consts, ctx.num_cam, ctx.W, ctx.vs, ctx.pt, ctx.with_silh = consts, num_cam, W, vs, pt, bool(with_silh)
-        ctx.Ws = Ws
+        ctx.Ws, ctx.VP = Ws, VP
         ctx.det = bool(deterministic)
         ctx.bounds = bounds
-        ctx.save_for_backward(x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot)
-        ctx.mark_non_differentiable(mask)
-        return verts, proj, mask, seg, silh, Jt
+        ctx.has_seg, ctx.has_loss = bool(opts.seg), loss_spec is not None
+        E = none
+        saved = [x, Rs, J, A, v_posed, proj if with_silh else E(), arg if opts.seg else E(), rec if opts.seg else E(),
+                 silh if with_silh else E(), sarg if with_silh else E(), vslot if opts.seg else E(),
+                 stats if loss_spec is not None else E()]
+        ctx.save_for_backward(*saved)
+        outs = [t if t is not None else E() for t in (verts, proj, mask, seg, silh, Jt, loss)]
+        ctx.mark_non_differentiable(outs[2])
+        if loss_spec is not None:
+            ctx.mark_non_differentiable(outs[3])         # with a fused loss the scores are a by-product, not a path
+        return tuple(outs)
 
     @staticmethod
     @on_device
-    def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt):
-        x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot = ctx.saved_tensors
-        dseg = require_cuda(dseg, "dseg") if dseg is not None else None
+    def backward(ctx, dverts, dproj_in, _dmask, dseg, dsilh, dJt, dloss):
+        x, Rs, J, A, v_posed, proj, arg, rec, silh, sarg, vslot, stats = ctx.saved_tensors
+        dseg = require_cuda(dseg, "dseg") if (dseg is not None and ctx.has_seg and not ctx.has_loss) else None
+        dloss = require_cuda(dloss, "dloss") if (dloss is not None and ctx.has_loss) else None
         dsilh = require_cuda(dsilh, "dsilh") if (ctx.with_silh and dsilh is not None) else None
         dproj_in = require_cuda(dproj_in, "dproj") if dproj_in is not None else None
         dverts = require_cuda(dverts, "dverts") if dverts is not None else None
         dJt = require_cuda(dJt, "dJ_transformed") if dJt is not None else None
-        VP = proj.shape[1]
+        VP = ctx.VP
         dx = _empty(tuple(x.shape), x)
 
         def run(lo, hi):
@@ -889,6 +1013,10 @@ class DecoderFn(torch.autograd.Function):
                 # the slot sums stay in the workspace; the skinning backward gathers them by vertex
                 part, nsplit = _seg_bwd(dseg[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt, merge=False,
                                         deterministic=ctx.det)
+                seg_grad = (part, vslot[lo:hi], nsplit)
+            elif dloss is not None:
+                part, nsplit = _seg_loss_bwd(dloss[lo:hi], stats[lo:hi], arg[lo:hi], rec[lo:hi], VP, ctx.W, ctx.pt,
+                                             merge=False, deterministic=ctx.det)
                 seg_grad = (part, vslot[lo:hi], nsplit)
             if dsilh is not None:
                 d2 = _silh_bwd(dsilh[lo:hi], silh[lo:hi], sarg[lo:hi], proj[lo:hi], ctx.Ws, ctx.det)
@@ -903,4 +1031,16 @@ class DecoderFn(torch.autograd.Function):
 
         if x.shape[0] > 0:
             _run_chunks(ctx.bounds, x.device, run)
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
+
+
+@on_device
+def _skin_vis_seg_opt(v_posed, A, c, cam, W, pt, grid_wh, ref_compat, verts, proj, mask, seg, arg, rec, vslot):
+    """smplr_skin_vis_seg_fwd with optional verts / proj / mask (None = not written)."""
+    lib = _lib.load()
+    B, V = v_posed.shape[0], c.V
+    ws = _workspace(lib.smplr_seg_workspace(B, V, W, pt.P, pt.K), v_posed)
+    check(lib.smplr_skin_vis_seg_fwd(ptr(v_posed), ptr(c.lbs_top4), ptr(A), ptr(cam), cam.shape[1], B, V, W,
+                                     int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos), ptr(pt.part_off), pt.P,
+                                     pt.K, ptr(ws), ptr(verts), ptr(proj), ptr(mask), ptr(seg), ptr(arg), ptr(rec),
+                                     ptr(vslot), stream()), "smplr_skin_vis_seg_fwd")

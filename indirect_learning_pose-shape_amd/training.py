@@ -26,31 +26,51 @@ class SegTrainer:
 
     def __init__(self, smpl_path=None, input_wh=256, output_wh=48, encoder_architecture="enet", use_IEF=True,
                  weight_classes=True, gamma=2.0, lr=1e-4, device=None, ddp=False, bucket_mb=25,
-                 with_silhouette=False, silh_wh=None):
+                 with_silhouette=False, silh_wh=None, fused_loss=True):
         self.device = (torch.device(device) if device is not None
                        else torch.device("cuda", torch.cuda.current_device()))
         self.output_wh = output_wh
         self.smpl_model = SMPLRegressor(output_wh, encoder_architecture, use_IEF).to(self.device)
-        self.decoder = SMPLDecoder(smpl_path, img_wh=output_wh, with_silhouette=with_silhouette, silh_wh=silh_wh)
+        self.loss_fn = softmax_focal_loss(gamma, weight_classes)      # softmax + focal loss, one HIP kernel
+        self.silh_loss_fn = softmax_focal_loss(0.0, False)            # softmax + categorical CE
+        # the train pass consumes losses only: verts / projects / mask are not written out, and with an integer class
+        # map the segmentation loss runs inside the rasteriser (no (B,W,W,32) score or gradient tensor in memory)
+        self.decoder = SMPLDecoder(smpl_path, img_wh=output_wh, with_silhouette=with_silhouette, silh_wh=silh_wh,
+                                   outputs=(), loss=self.loss_fn if fused_loss else None)
         self.with_silhouette = with_silhouette
+        # the silhouette-only pass of the reference's alternating schedule (train_stage2_silhouette.py:262-270)
+        self.silh_decoder = (SMPLDecoder(smpl_path, img_wh=output_wh, heads=("silhouette",), silh_wh=silh_wh, outputs=())
+                             .share_constants(self.decoder)) if with_silhouette else None
         self.net = self.smpl_model
         if ddp:
             self.net = nn.parallel.DistributedDataParallel(
                 self.smpl_model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
-        self.loss_fn = softmax_focal_loss(gamma, weight_classes)      # softmax + focal loss, one HIP kernel
-        self.silh_loss_fn = softmax_focal_loss(0.0, False)            # softmax + categorical CE
         self.opt = torch.optim.Adam(self.smpl_model.parameters(), lr=lr)       # train.py:179
 
     def step(self, images, labels, silh_labels=None):
-        """images (N,3,H,W) or (N,H,W,3); labels (N,W,W) integer class map or (N,W*W,32) one-hot.
+        """images (N,3,H,W) or (N,H,W,3); labels (N,W,W) integer class map or (N,W*W,32) one-hot, or None for the
+        silhouette-only step of the alternating schedule (then silh_labels is required).
         Returns the mean loss (a 0-d tensor; no host sync)."""
         self.opt.zero_grad(set_to_none=True)
         param = self.net(images)
-        out = self.decoder(param)
-        loss = self.loss_fn(labels, out["seg"]).mean()             # model.py:119-120 + focal_loss.py
-        if self.with_silhouette and silh_labels is not None:      # train_stage2_silhouette.py:85-86,226-229
-            loss = loss + self.silh_loss_fn(silh_labels, out["silhouette"]).mean()
+        if labels is None:
+            # `silhouettes_model.fit` (train_stage2_silhouette.py:226-234, the 150 silhouette steps of :262-270):
+            # the silhouette head alone - no mask, no binning, no 31-part rasteriser
+            if self.silh_decoder is None or silh_labels is None:
+                raise RuntimeError("a step without labels is the silhouette-only step: needs with_silhouette and silh_labels")
+            out = self.silh_decoder(param)
+            loss = self.silh_loss_fn(silh_labels, out["silhouette"]).mean()
+        else:
+            is_map = labels.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8)
+            if self.decoder.loss is not None and is_map:           # model.py:119-120 + focal_loss.py, in the rasteriser
+                loss = self.decoder(param, labels)
+                out, loss = loss, loss["seg_loss"].mean()
+            else:
+                out = self.decoder(param)
+                loss = self.loss_fn(labels, out["seg"]).mean()
+            if self.with_silhouette and silh_labels is not None:  # train_stage2_silhouette.py:85-86,226-229
+                loss = loss + self.silh_loss_fn(silh_labels, out["silhouette"]).mean()
         loss.backward()
         self.opt.step()
         return loss.detach()

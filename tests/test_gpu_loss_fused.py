@@ -1,0 +1,246 @@
+"""The loss head fused into the rasteriser (model.py:119-120 + focal_loss.py:10-46):
+smplr_seg_raster_loss / smplr_skin_vis_seg_loss_fwd / smplr_seg_loss_bwd against the float64 oracle
+(np_oracle.categorical_focal_loss on np_oracle.projects_to_seg; gradients: torch_oracle autograd) and against the
+unfused HIP path (scores written out, smplr_focal_fwd/bwd, smplr_seg_bwd).
+
+Tolerances: the per-pixel loss against the oracle evaluated on the HIP path's OWN scores 1e-4 relative (fp32
+softmax + log against float64, as for the unfused head); end to end against the oracle's scores 2e-3 (scores carry
+the 1e-3 relative bar of north_star); gradients as the rasteriser's other backward tests (grad_close 2e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from _inputs import make_x
+from test_gpu_parity import dev, grad_close, t
+
+pytestmark = pytest.mark.gpu
+
+# (gamma, class weights): the unfused head's label-map parametrisations (tests/test_gpu_parity.py) + two more
+PARAMS = [(2.0, True), (2.0, False), (1.5, True), (0.0, False), (1.0, True), (0.0, True)]
+
+
+@pytest.fixture(scope="module")
+def layer(smpl_model):
+    from ilps_amd.keras_smpl.batch_smpl import SMPLLayer
+    return SMPLLayer(smpl_model)
+
+
+def _proj_mask(layer, B, W, seed):
+    from ilps_amd.keras_smpl.compute_mask import compute_mask
+    from ilps_amd.keras_smpl.projection import orthographic_project
+    x = t(make_x(B, W, seed=seed))
+    with torch.no_grad():
+        proj = orthographic_project([layer(x), x], None).contiguous()
+        mask = compute_mask(proj)
+    return proj, mask
+
+
+def _labels(rng, B, W, seg=None):
+    """Random labels, half of them replaced by the arg-max class where scores are given (a realistic map)."""
+    lab = rng.integers(0, 32, (B, W, W))
+    if seg is not None:
+        am = seg.argmax(-1)
+        pick = rng.random((B, W, W)) < 0.5
+        lab = np.where(pick, am, lab)
+    return lab.astype(np.int64)
+
+
+@pytest.mark.parametrize("gamma,weighted", PARAMS)
+@pytest.mark.parametrize("W", [48, 50])
+def test_fused_loss_stage_parity(layer, part_tables, W, gamma, weighted):
+    """Binning + rasteriser with the loss epilogue + the fused backward, through the raw stage calls (the C ABI)."""
+    from ilps_amd import ops
+    from oracle import np_oracle as o
+    from oracle import torch_oracle as to
+    B = 3
+    proj, mask = _proj_mask(layer, B, W, seed=int(10 * gamma) + W)
+    pt = ops.get_part_table(1, proj.device, 6890)
+    ws, rec = ops._seg_bin(proj, mask, W, pt)                                # mask is an input here (grid_wh = 0)
+    seg_ref, arg_ref = ops._seg_raster(ws, rec, B, W, pt)
+    rng = np.random.default_rng(W + int(gamma * 7))
+    lab = _labels(rng, B, W, seg_ref.cpu().numpy())
+    w64 = o.FOCAL_CLASS_WEIGHTS[:32] if weighted else None
+    cw = t(w64) if weighted else None
+    seg = torch.empty_like(seg_ref)
+    loss, stats, arg = ops._seg_raster_loss(ws, rec, B, W, pt, t(lab, torch.int32), cw, gamma, seg=seg)
+    torch.cuda.synchronize()
+    # the epilogue changes nothing of what the rasteriser writes
+    assert torch.equal(seg, seg_ref) and torch.equal(arg, arg_ref)
+    # a second launch without the score tensor gives the same loss and stats, bit for bit
+    loss2, stats2, arg2 = ops._seg_raster_loss(ws, rec, B, W, pt, t(lab, torch.int32), cw, gamma, seg=None)
+    assert torch.equal(loss2, loss) and torch.equal(stats2, stats) and torch.equal(arg2, arg)
+    y = np.eye(32)[lab.reshape(B, -1)]
+    # (a) the loss formula on the HIP path's own scores, in float64
+    want_a = o.categorical_focal_loss(y, o.softmax_last(seg.cpu().numpy().astype(np.float64)), gamma, weighted)
+    got = loss.cpu().numpy()
+    assert got.shape == (B, W * W)
+    assert np.all(np.abs(got - want_a) <= 1e-4 * np.abs(want_a) + 1e-7)
+    # (b) end to end against the oracle's scores
+    ids, off = part_tables[1]
+    p64, m64 = proj.cpu().numpy().astype(np.float64), mask.cpu().numpy().astype(np.float64)
+    want_b = o.categorical_focal_loss(y, o.softmax_last(o.projects_to_seg(p64, m64, W, ids, off)), gamma, weighted)
+    assert np.all(np.abs(got - want_b) <= 2e-3 * np.abs(want_b) + 1e-6)
+    # stats: label bits, background score, sign = the clip's gate
+    st = stats.cpu().numpy()
+    assert np.array_equal(st[..., 3].view(np.int32).reshape(B, W, W), lab.astype(np.int32))
+    assert np.array_equal(st[..., 1].reshape(B, W, W), seg.cpu().numpy()[..., 0])
+    gate = arg.cpu().numpy()[..., 0] == 1
+    assert np.array_equal(st[..., 0].reshape(B, W, W) > 0, gate)
+    # backward: dproj against float64 autograd through projects_to_seg + softmax + focal loss
+    cot = rng.normal(0, 1, (B, W * W))
+    dproj = ops._seg_loss_bwd(t(cot), stats, arg, rec, 6890, W, pt, merge=True)
+    po = torch.tensor(p64, requires_grad=True)
+    s64 = to.projects_to_seg(po, torch.tensor(m64), W, ids, off)
+    l64 = to.softmax_focal_loss(s64, torch.tensor(y), gamma, torch.tensor(w64) if weighted else None)
+    (l64 * torch.tensor(cot)).sum().backward()
+    grad_close(dproj.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(fused loss, W=%d)" % W, per_column=False)
+    # ... and against the unfused HIP path (scores -> smplr_focal_bwd -> smplr_seg_bwd)
+    sd = seg_ref.clone().requires_grad_(True)
+    lu = ops.SoftmaxFocalFn.apply(sd, t(lab.reshape(B, -1), torch.int64), cw, gamma)
+    (lu * t(cot)).sum().backward()
+    dproj_u = ops._seg_bwd(sd.grad.contiguous(), arg_ref, rec, 6890, W, pt, merge=True)
+    assert np.all(np.abs(got - lu.detach().cpu().numpy()) <= 1e-5 * np.abs(want_a) + 1e-7)
+    grad_close(dproj.cpu().numpy(), dproj_u.cpu().numpy(), 2e-4, "dproj fused vs unfused", per_column=False)
+
+
+def test_fused_loss_kats(layer):
+    """Labels outside the 32 classes contribute no loss and no gradient (as smplr_focal_fwd's one-hot of such an id);
+    an all-background label map and an all-one-part label map against the float64 formula; deterministic = 1 gives
+    the same gradient bit for bit on every launch and agrees with the default form."""
+    from ilps_amd import ops
+    from oracle import np_oracle as o
+    B, W = 2, 48
+    proj, mask = _proj_mask(layer, B, W, seed=5)
+    pt = ops.get_part_table(1, proj.device, 6890)
+    ws, rec = ops._seg_bin(proj, mask, W, pt)
+    seg = torch.empty(B, W, W, 32, device=dev())
+    for fill in (0, 7):
+        lab = np.full((B, W, W), fill, np.int64)
+        loss, stats, arg = ops._seg_raster_loss(ws, rec, B, W, pt, t(lab, torch.int32), None, 2.0, seg=seg)
+        want = o.categorical_focal_loss(np.eye(32)[lab.reshape(B, -1)], o.softmax_last(seg.cpu().numpy().astype(np.float64)), 2.0)
+        assert np.all(np.abs(loss.cpu().numpy() - want) <= 1e-4 * np.abs(want) + 1e-7)
+    lab = np.random.default_rng(0).integers(0, 32, (B, W, W))
+    lab[0, :10] = 32
+    lab[1, 5:9] = -1
+    lab[1, 20] = 1000
+    loss, stats, arg = ops._seg_raster_loss(ws, rec, B, W, pt, t(lab, torch.int32), None, 2.0, seg=seg)
+    bad = (lab < 0) | (lab > 31)
+    got = loss.cpu().numpy().reshape(B, W, W)
+    assert np.all(got[bad] == 0.0) and np.all(got[~bad] > 0.0)
+    assert np.all(stats.cpu().numpy()[..., 2].reshape(B, W, W)[bad] == 0.0)          # q_t softmax_t = 0: no gradient
+    cot = t(np.random.default_rng(1).normal(0, 1, (B, W * W)))
+    d_all = ops._seg_loss_bwd(cot, stats, arg, rec, 6890, W, pt, merge=True)
+    cz = cot.clone().reshape(B, W, W)
+    cz[t(bad, torch.bool)] = 0.0                                   # zeroing their cotangents changes nothing
+    d_zero = ops._seg_loss_bwd(cz.reshape(B, -1).contiguous(), stats, arg, rec, 6890, W, pt, merge=True)
+    grad_close(d_all.cpu().numpy(), d_zero.cpu().numpy(), 1e-6, "bad labels carry no gradient", per_column=False)
+    d1 = ops._seg_loss_bwd(cot, stats, arg, rec, 6890, W, pt, merge=True, deterministic=True)
+    d2 = ops._seg_loss_bwd(cot, stats, arg, rec, 6890, W, pt, merge=True, deterministic=True)
+    assert torch.equal(d1, d2)
+    grad_close(d1.cpu().numpy(), d_all.cpu().numpy(), 1e-5, "deterministic vs default", per_column=False)
+
+
+def test_fused_loss_argument_errors(layer):
+    from ilps_amd import _lib, ops
+    lib = _lib.load()
+    # P != 31 or a negative gamma are refused before any launch
+    one = torch.zeros(4, device=dev())
+    rc = lib.smplr_seg_raster_loss(1, 48, 17, 100, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, 2.0, None,
+                                   _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None)
+    assert rc == -1 and b"32-class" in lib.smplr_last_error()
+    rc = lib.smplr_seg_raster_loss(1, 48, 31, 6879, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, -1.0, None,
+                                   _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None)
+    assert rc == -1 and b"gamma" in lib.smplr_last_error()
+    rc = lib.smplr_seg_loss_bwd(None, None, None, None, 1, 6890, 48, 31, 6879, None, None, 0, None)
+    assert rc == -1 and b"dloss" in lib.smplr_last_error()
+    assert lib.smplr_seg_loss_bwd(None, None, None, None, 0, 6890, 48, 31, 6879, None, None, 0, None) == 0
+
+
+@pytest.mark.parametrize("B,W,with_silh", [(3, 48, False), (128, 48, False), (5, 48, True), (2, 64, False), (2, 128, False)])
+def test_decoder_with_fused_loss_equals_unfused(smpl_model, B, W, with_silh):
+    """SMPLDecoder(loss=softmax_focal_loss(...)): forward(x, labels) returns the per-pixel loss without ever writing
+    the scores; loss and dx agree with the unfused decoder + loss head.  W = 128 takes the two-call path (the
+    skinning form of the binning kernel does not fit there), B = 128 is BASELINE configs[2]'s batch."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.focal_loss import softmax_focal_loss
+    x = make_x(B, W, seed=B + W)
+    lf = softmax_focal_loss(2.0, True)
+    plain = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh)
+    fused = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, loss=lf, outputs=(), keep_seg=True)
+    rng = np.random.default_rng(B)
+    xa = t(x).requires_grad_(True)
+    oa = plain(xa)
+    lab = t(_labels(rng, B, W, oa["seg"].detach().cpu().numpy()), torch.int64)
+    cot = t(rng.normal(0, 1, (B, W * W)) / (B * W * W))
+    gl = t(rng.normal(0, 1, (B, W, W, 2)) / (B * W * W))
+    la = lf(lab, oa["seg"])
+    tot = (la * cot).sum()
+    if with_silh:
+        tot = tot + (oa["silhouette"] * gl).sum()
+    tot.backward()
+    xb = t(x).requires_grad_(True)
+    ob = fused(xb, lab)
+    assert set(ob) == {"J_transformed", "seg_loss", "seg"} | ({"silhouette"} if with_silh else set())
+    tot = (ob["seg_loss"] * cot).sum()
+    if with_silh:
+        tot = tot + (ob["silhouette"] * gl).sum()
+    tot.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(ob["seg"], oa["seg"].detach())
+    a, b = la.detach().cpu().numpy(), ob["seg_loss"].detach().cpu().numpy()
+    assert np.all(np.abs(a - b) <= 1e-5 * np.abs(a) + 1e-7)
+    grad_close(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), 1e-3, "dx fused vs unfused loss (B=%d, W=%d)" % (B, W))
+    # without labels the same decoder returns the scores (the unfused path)
+    with torch.no_grad():
+        assert torch.equal(fused(t(x))["seg"], oa["seg"].detach())
+
+
+def test_silhouette_only_decoder(smpl_model):
+    """heads=("silhouette",): no mask, no binning, no 31-part rasteriser; silhouette and dx equal to the two-head
+    decoder's silhouette branch."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.focal_loss import softmax_focal_loss
+    B, W = 7, 48
+    x = make_x(B, W, seed=3)
+    both = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=True)
+    only = SMPLDecoder(smpl_model, img_wh=W, heads=("silhouette",), outputs=("verts",)).share_constants(both)
+    g = t(np.random.default_rng(4).normal(0, 1, (B, W, W, 2)))
+    xa = t(x).requires_grad_(True)
+    oa = both(xa)
+    (oa["silhouette"] * g).sum().backward()
+    xb = t(x).requires_grad_(True)
+    ob = only(xb)
+    assert set(ob) == {"J_transformed", "verts", "silhouette"}
+    (ob["silhouette"] * g).sum().backward()
+    assert torch.equal(ob["silhouette"], oa["silhouette"]) and torch.equal(ob["verts"], oa["verts"])
+    grad_close(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), 1e-5, "dx silhouette-only vs two heads")
+    with pytest.raises(ValueError):
+        SMPLDecoder(smpl_model, heads=())
+    with pytest.raises(ValueError):
+        SMPLDecoder(smpl_model, heads=("silhouette",), loss=softmax_focal_loss())
+
+
+def test_trainer_fused_loss_equals_unfused(smpl_model):
+    """SegTrainer runs the loss inside the rasteriser for integer class maps: the first step's loss and the encoder
+    gradients equal the unfused trainer's (same initial weights, eval-mode statistics so that both see the same
+    network), and the silhouette-only step of the alternating schedule runs."""
+    from ilps_amd.training import SegTrainer
+    B, W = 4, 48
+    torch.manual_seed(3)
+    images = torch.rand(B, 3, 256, 256, device=dev())
+    labels = torch.randint(0, 32, (B, W, W), device=dev())
+    silh_labels = torch.randint(0, 2, (B, W, W), device=dev())
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        tr = SegTrainer(smpl_model, output_wh=W, encoder_architecture="enet", use_IEF=True, device=dev(),
+                        with_silhouette=True, fused_loss=fused)
+        tr.smpl_model.eval()
+        loss = tr.step(images, labels, silh_labels)
+        grads = [p.grad.detach().clone() for p in tr.smpl_model.parameters() if p.grad is not None]
+        res.append((float(loss), grads))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12
+    l3 = tr.step(images, None, silh_labels)                        # silhouettes_model.fit's step
+    assert np.isfinite(float(l3))

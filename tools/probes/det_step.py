@@ -13,7 +13,7 @@ pt = ops.get_part_table(1, dev, c.V)
 x = torch.tensor(bench.make_x(B, 48, 77), device=dev)
 g = torch.randn(B, 48, 48, 32, device=dev)
 gl = torch.randn(B, 48, 48, 2, device=dev)
-names = ["verts", "proj", "mask", "seg", "silh", "Jt", "dx"]
+names = ["verts", "proj", "mask", "seg", "silh", "Jt", "loss", "dx"]
 def step():
     xg = x.detach().requires_grad_(True)
     outs = ops.DecoderFn.apply(xg, c, 4, 48, 1, pt, 64, True, True, 1, det)

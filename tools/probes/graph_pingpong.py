@@ -17,7 +17,7 @@ dseg = torch.randn(B, W, W, 32, device=dev)
 
 def step():
     xg = x.detach().requires_grad_(True)
-    verts, proj, mask, seg, silh, jt = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1)
+    verts, proj, mask, seg, silh, jt, _ls = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False, 1)
     seg.backward(dseg)
     return xg.grad
 
