@@ -544,6 +544,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="meshes per GPU")
     ap.add_argument("--wh", type=int, default=48)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--graph-steps", type=int, default=10,
+                    help="graph mode: whole steps captured per graph launch (cut to a divisor of --steps)")
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent mesh chunks per step (HIP streams / parallel graph branches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -612,7 +614,14 @@ def main():
     mode = args.mode
     run = step
     graph = None
+    # `--graph-steps G` whole steps are captured per graph launch (each a full forward + backward of all B meshes, one
+    # after the other on one stream): the ~3 us between two launches of a graph is paid once per G steps.  G is cut
+    # to a divisor of --steps so that EXACTLY --steps steps run in the timed window.
+    gsteps = 1
     if mode == "graph":
+        gsteps = max(1, min(int(args.graph_steps), args.steps))
+        while args.steps % gsteps:
+            gsteps -= 1
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -623,23 +632,28 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_grad = step()
+                for _ in range(gsteps):
+                    static_grad = step()
             run = graph.replay
         except Exception as e:  # capture unsupported -> eager, reported in config
             sys.stderr.write("bench: HIP graph capture failed (%s); running eager\n" % e)
             mode = "eager"
             graph = None
+            gsteps = 1
             run = step
             torch.cuda.synchronize()
+    nrun, nwarm = args.steps // gsteps, -(-max(args.warmup, 200) // gsteps)   # launches of `run` = steps / gsteps
 
-    for _ in range(args.warmup):
+    # untimed: the W warm-up steps asked for, and at least 200 (30 ms of replays) so that the GPU's clock has settled
+    # before the timed window (with 10 the first window of 50 steps read 5 % over the nine that followed it)
+    for _ in range(nwarm):
         run()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(nrun):
         run()
     torch.cuda.synchronize()
     if dist:
@@ -653,7 +667,7 @@ def main():
     # the spread: further windows of the same K steps, same bracketing (the first window above is `value`)
     windows = [elapsed / args.steps * 1e3]
     for _ in range(max(0, args.windows - 1)):
-        windows.append(_timed_steps(run, 0, args.steps, dist, dev, backend, torch.cuda.synchronize) / args.steps * 1e3)
+        windows.append(_timed_steps(run, 0, nrun, dist, dev, backend, torch.cuda.synchronize) / args.steps * 1e3)
     # the design's one collective: the data-parallel train step (every rank takes part)
     tleg = None
     if not args.no_train_leg:
@@ -681,7 +695,8 @@ def main():
             "config": {"workload": "full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
                                    "projects_to_seg), BASELINE configs[2]",
                        "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,
-                       "params_per_mesh": 86, "launch": mode, "concurrent_chunks": args.streams,
+                       "params_per_mesh": 86, "launch": mode, "steps_per_graph_launch": gsteps,
+                       "concurrent_chunks": args.streams,
                        "blend_gemm": ("bf16x3: fp32 operands as 3 bf16 terms (24 significant bits), 6 partial "
                                       "products, fp32 accumulation" if ops.blend_gemm_mode() == "bf16x3"
                                       else "fp32 MFMA"),

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from _inputs import make_x
+from _inputs import argmin_disagreements, make_x
 from test_gpu_parity import dev, grad_close, t
 
 pytestmark = pytest.mark.gpu
@@ -93,7 +93,23 @@ def test_fused_loss_stage_parity(layer, part_tables, W, gamma, weighted):
     s64 = to.projects_to_seg(po, torch.tensor(m64), W, ids, off)
     l64 = to.softmax_focal_loss(s64, torch.tensor(y), gamma, torch.tensor(w64) if weighted else None)
     (l64 * torch.tensor(cot)).sum().backward()
-    grad_close(dproj.cpu().numpy(), po.grad.numpy(), 2e-3, "dproj(fused loss, W=%d)" % W, per_column=False)
+    # (where fp32 and float64 pick different arg-min vertices - near-ties, each one verified to be one - the gradient
+    # of that pixel goes to another vertex: those vertices are compared by the max-norm bar only; here one pixel can
+    # carry a visible share of a vertex' sum, the labelled channel's gradient being ~30 x any other channel's)
+    ws64, warg = o.projects_to_seg(p64, m64, W, ids, off, return_argmin=True)
+    garg = ops.argmin_vertices(arg, rec).cpu().numpy()
+    ndiff, bad = argmin_disagreements(garg, warg, ws64, p64, m64, W)
+    assert bad == 0 and ndiff <= 64, (ndiff, bad)
+    got_d, want_d = dproj.cpu().numpy(), po.grad.numpy()
+    assert np.abs(got_d - want_d).max() <= 2e-3 * np.abs(want_d).max()
+    tied = np.zeros((B, 6890), bool)
+    for n, ro, c, p in np.argwhere((garg != warg) & (ws64[..., 1:] >= 1e-30)):
+        tied[n, warg[n, ro, c, p]] = True
+        if garg[n, ro, c, p] >= 0:
+            tied[n, garg[n, ro, c, p]] = True
+    keep = ~tied[..., None] & np.ones((1, 1, 3), bool)
+    grad_close(np.where(keep, got_d, 0.0), np.where(keep, want_d, 0.0), 2e-3, "dproj(fused loss, W=%d)" % W,
+               per_column=False)
     # ... and against the unfused HIP path (scores -> smplr_focal_bwd -> smplr_seg_bwd)
     sd = seg_ref.clone().requires_grad_(True)
     lu = ops.SoftmaxFocalFn.apply(sd, t(lab.reshape(B, -1), torch.int64), cw, gamma)

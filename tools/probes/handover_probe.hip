@@ -7,8 +7,8 @@
 //   P1  ONE producer wave: ds_write payload -> s_waitcnt lgkmcnt(0) -> volatile store of the step; consumer:
 //       volatile poll -> plain loads.  (the "obvious" form)
 //   P2  the same with release / acquire atomics at workgroup scope
-//   P3  TWO producer waves each write half of the payload; wave 0 alone publishes after ITS OWN wait
-//       (what round 2's producers did: "two waves per tile ... published a step counter")
+//   P3  TWO producer waves each write half of the payload (wave 1 late by a varying amount, as under uneven load);
+//       wave 0 alone publishes after ITS OWN wait - the flaw a step counter written by one of several producers has
 //   P4  two producer waves, each adds 1 to the counter (release) after its own wait; the consumer waits for 2 per step
 // A protocol passes with 0 mismatching words.  The payload is 4 KB (16 B per lane per wave-store, 4 stores), new
 // values every step; the consumer acknowledges a step through a second word so that the producers may overwrite.
@@ -29,6 +29,7 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 constexpr int PAY = 1024;          // payload dwords (4 KB)
 constexpr unsigned SPIN_MAX = 1u << 22;
 
@@ -54,6 +55,10 @@ __global__ __launch_bounds__(512) void lds_handover(int steps, unsigned *bad_out
       unsigned spin = 0;
       while (__hip_atomic_load(&ack, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(s - 1) && ++spin < SPIN_MAX) {}
       if (spin >= SPIN_MAX) { timed_out = 1; break; }
+      if (two && wave == 1) {                                        // uneven load: producer 1 is late by a varying amount
+        unsigned z = (unsigned)s * 747796405u + wg;
+        for (unsigned k = 0; k < (z >> 26); ++k) __builtin_amdgcn_s_sleep(4);
+      }
       const int half = two ? PAY / 2 : PAY, base = two ? wave * (PAY / 2) : 0;
       for (int i = lane * 4; i < half; i += 256) {
         uint4 v;
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(512) void lds_handover(int steps, unsigned *bad_out
 
 // ---- part 2: two workgroups exchange 32 KB through global memory, both directions, `steps` times
 constexpr int XW = 8192;           // dwords per direction (32 KB)
+template <bool SC1>   // SC1: write-through stores + L1-bypassing loads (the guide's R1 form) instead of release / acquire fences
 __global__ __launch_bounds__(1024) void wg_exchange(unsigned *buf /*[nwg][2][XW]*/, unsigned *flags /*[nwg]*/, int steps, int stride,
                                                    unsigned *bad_out, unsigned *timeout_out,
                                                    unsigned long long *cost /*[nwg][steps]*/) {
@@ -119,25 +125,40 @@ __global__ __launch_bounds__(1024) void wg_exchange(unsigned *buf /*[nwg][2][XW]
     for (int i = tid * 4; i < XW; i += 4096) {
       uint4 v;
       v.x = word(s, i, wg); v.y = word(s, i + 1, wg); v.z = word(s, i + 2, wg); v.w = word(s, i + 3, wg);
-      *reinterpret_cast<uint4 *>(mine + i) = v;
+      if (SC1) {
+        const u32x4v vv = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + i), "v"(vv) : "memory");
+      }
+      else *reinterpret_cast<uint4 *>(mine + i) = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __hip_atomic_store(&flags[wg], (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       unsigned spin = 0;
       while (__hip_atomic_load(&flags[peer], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s && ++spin < SPIN_MAX)
         __builtin_amdgcn_s_sleep(1);
       if (spin >= SPIN_MAX) s_to = 1;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
     if (s_to) break;                                                // (block-uniform: set before the barrier)
     for (int i = tid * 4; i < XW; i += 4096) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(theirs + i);
+      uint4 v;
+      if (SC1) {
+        u32x4v vv;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(vv) : "v"(theirs + i) : "memory");
+        v.x = vv.x; v.y = vv.y; v.z = vv.z; v.w = vv.w;
+      } else {
+        v = *reinterpret_cast<const uint4 *>(theirs + i);
+      }
       bad += (v.x != word(s, i, peer)) + (v.y != word(s, i + 1, peer)) + (v.z != word(s, i + 2, peer)) + (v.w != word(s, i + 3, peer));
     }
     if (tid == 0) cost[(size_t)wg * steps + (s - 1)] = clock64() - t0;
@@ -174,23 +195,27 @@ int main() {
 
   const int nwg = 256, xsteps = 400;
   unsigned long long total_bad = 0;
-  for (int stride : {1, 8}) {
+  for (int variant = 0; variant < 4; ++variant) {
+    const int stride = (variant & 1) ? 8 : 1;
+    const bool sc1 = variant >= 2;
     unsigned *buf, *flags, *bad, *to; unsigned long long *cost;
     CHECK(hipMalloc(&buf, (size_t)nwg * 2 * XW * 4)); CHECK(hipMalloc(&flags, nwg * 4)); CHECK(hipMalloc(&bad, nwg * 4));
     CHECK(hipMalloc(&to, 4)); CHECK(hipMalloc(&cost, (size_t)nwg * xsteps * 8));
     CHECK(hipMemset(buf, 0, (size_t)nwg * 2 * XW * 4)); CHECK(hipMemset(flags, 0, nwg * 4)); CHECK(hipMemset(bad, 0, nwg * 4));
     CHECK(hipMemset(to, 0, 4));
-    hipLaunchKernelGGL(wg_exchange, dim3(nwg), dim3(1024), 0, 0, buf, flags, xsteps, stride, bad, to, cost);
+    if (sc1) hipLaunchKernelGGL(wg_exchange<true>, dim3(nwg), dim3(1024), 0, 0, buf, flags, xsteps, stride, bad, to, cost);
+    else hipLaunchKernelGGL(wg_exchange<false>, dim3(nwg), dim3(1024), 0, 0, buf, flags, xsteps, stride, bad, to, cost);
     CHECK(hipDeviceSynchronize());
     std::vector<unsigned> hb(nwg); unsigned hto = 0; std::vector<unsigned long long> hc((size_t)nwg * xsteps);
     CHECK(hipMemcpy(hb.data(), bad, nwg * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&hto, to, 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(hc.data(), cost, hc.size() * 8, hipMemcpyDeviceToHost));
     unsigned long long words = 0; for (unsigned v : hb) words += v;
     std::sort(hc.begin(), hc.end());
-    printf("GLOBAL two workgroups (block b and b ^ %d: %s) exchange 32 KB each way (plain stores, agent release / acquire, "
+    printf("GLOBAL two workgroups (block b and b ^ %d: %s) exchange 32 KB each way (%s, "
            "one flag per workgroup): %d pairs x %d steps: %llu mismatching words, %u timeouts; cost per exchange "
            "(write + flag + wait + read) median %llu, p90 %llu, max %llu shader clocks\n",
-           stride, stride == 1 ? "different XCDs" : "same XCD", nwg / 2, xsteps, words, hto, hc[hc.size() / 2],
+           stride, stride == 1 ? "different XCDs" : "same XCD",
+           sc1 ? "sc1 write-through stores, drained; sc1 loads" : "plain stores, agent release / acquire fences", nwg / 2, xsteps, words, hto, hc[hc.size() / 2],
            hc[hc.size() * 9 / 10], hc.back());
     total_bad += words + hto;
     CHECK(hipFree(buf)); CHECK(hipFree(flags)); CHECK(hipFree(bad)); CHECK(hipFree(to)); CHECK(hipFree(cost));
