@@ -187,7 +187,10 @@ def raster_roofline(x, consts, pt, W, stages):
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf) and B == 128 and W == 48:
         try:
-            k = json.load(open(tf))["kernels"].get("raster_fwd_kernel", {})
+            tj = json.load(open(tf))
+            k = tj["kernels"].get("raster_fwd_kernel", {})
+            # the committed counter passes are stamped with the library they were taken on
+            out["profile_build_id_matches"] = tj.get("build_id") == _lib.build_id()
             out["traffic"] = k.get("hbm_bytes_per_launch")
             out["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read-side x2)"
         except Exception:
@@ -544,6 +547,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="meshes per GPU")
     ap.add_argument("--wh", type=int, default=48)
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--step", default="default",
+                    choices=["default", "seg_only", "fused_loss", "unfused_loss", "both_heads", "silhouette_only"],
+                    help="time a variant of the decoder step (profiling); the headline is `default`")
     ap.add_argument("--graph-steps", type=int, default=10,
                     help="graph mode: whole steps captured per graph launch (cut to a divisor of --steps)")
     ap.add_argument("--streams", type=int, default=1,
@@ -610,6 +616,41 @@ def main():
                                                                args.streams)
         seg.backward(dseg)
         return xg.grad
+
+    # `--step` other than "default" times a VARIANT of the decoder step instead (for the profile passes, which trace
+    # whatever this process runs): the line then says so in `config.workload` and is not the headline
+    variant_note = None
+    if args.step != "default":
+        from ilps_amd.focal_loss import class_weights
+        labs_v = torch.randint(0, 32, (B, W, W), device=dev, dtype=torch.int32)
+        dlp_v = torch.full((B, W * W), 1.0 / (B * W * W), device=dev)
+        dsl_v = torch.randn(B, W, W, 2, device=dev)
+        quiet = dict(want_verts=False, want_proj=False, want_mask=False)
+        v_opts = {"seg_only": ops.DecoderOpts(**quiet),
+                  "fused_loss": ops.DecoderOpts(loss=(labs_v, class_weights(dev), 2.0), want_seg=False, **quiet),
+                  "unfused_loss": None, "both_heads": None,
+                  "silhouette_only": ops.DecoderOpts(want_verts=False, want_mask=False, seg=False)}[args.step]
+        silh_v = args.step in ("both_heads", "silhouette_only")
+        variant_note = {"seg_only": "decoder fwd+bwd without writing verts / proj / mask",
+                        "fused_loss": "decoder + softmax-focal loss fwd+bwd, loss head inside the rasteriser, no verts / proj / mask / seg written",
+                        "unfused_loss": "decoder + softmax-focal loss fwd+bwd, scores written, smplr_focal_fwd / bwd",
+                        "both_heads": "decoder fwd+bwd with the 31-part head and the silhouette head",
+                        "silhouette_only": "decoder fwd+bwd with the silhouette head alone"}[args.step]
+
+        def step():                                               # noqa: F811
+            xg = x.detach().requires_grad_(True)
+            o_ = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, silh_v, args.streams, False, v_opts)
+            if args.step == "fused_loss":
+                o_[6].backward(dlp_v)
+            elif args.step == "unfused_loss":
+                ops.SoftmaxFocalFn.apply(o_[3], labs_v, class_weights(dev), 2.0).backward(dlp_v)
+            elif args.step == "both_heads":
+                torch.autograd.backward([o_[3], o_[4]], [dseg, dsl_v])
+            elif args.step == "silhouette_only":
+                o_[4].backward(dsl_v)
+            else:
+                o_[3].backward(dseg)
+            return xg.grad
 
     mode = args.mode
     run = step
@@ -692,8 +733,9 @@ def main():
                                     "note": "the first window is `ms_per_step` / `value`; boxes differ by +-4 %"},
             "build_id": _lib.build_id(),
             "train_step": tleg,
-            "config": {"workload": "full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
-                                   "projects_to_seg), BASELINE configs[2]",
+            "config": {"workload": ("full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
+                                    "projects_to_seg), BASELINE configs[2]" if variant_note is None
+                                    else "VARIANT --step %s (not the headline): %s" % (args.step, variant_note)),
                        "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,
                        "params_per_mesh": 86, "launch": mode, "steps_per_graph_launch": gsteps,
                        "concurrent_chunks": args.streams,

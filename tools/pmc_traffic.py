@@ -11,7 +11,7 @@ import os
 import sys
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in sys.argv[1:]:
+for d in [a for a in sys.argv[1:]]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("smplr::", "").split("<")[0]
@@ -38,6 +38,14 @@ for k, cs in acc.items():
 seg = sum(out["kernels"].get(k, {}).get("hbm_bytes_per_launch", 0) for k in ("seg_bin_kernel", "raster_fwd_kernel"))
 out["seg_fwd_hbm_bytes_per_launch"] = seg
 out["seg_fwd_note"] = "seg_bin_kernel + raster_fwd_kernel (the two kernels of smplr_seg_fwd / smplr_vis_seg_fwd)"
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import ilps_amd  # noqa: E402,F401
+from ilps_amd import _lib  # noqa: E402
+out["build_id"] = _lib.source_build_id()        # the sources the measured library was built from (same tree)
+step = [k for k in out["kernels"] if "pack" not in k and "copy" not in k]
+out["step_hbm_bytes"] = sum(out["kernels"][k].get("hbm_bytes_per_launch", 0) for k in step)
+name = os.environ.get("PMC_TRAFFIC_NAME", "pmc_traffic.json")       # variants: PMC_TRAFFIC_NAME=r03_traffic_fused_loss.json
+path = os.path.join(root, "profiles", name)
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path, "seg_fwd bytes/launch", seg)

@@ -32,6 +32,11 @@ out = {"kernel": KERNEL, "kernel_us": us, "kernel_us_source": os.path.basename(s
        "units": "SQ_INSTS_* = wave-instructions; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* = quad-cycles (x4 = cycles), summed over the chip"}
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "raster_sq.json")
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import ilps_amd  # noqa: E402,F401
+from ilps_amd import _lib  # noqa: E402
+out["build_id"] = _lib.source_build_id()
+path = os.path.join(root, "profiles", "raster_sq.json")
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path, {k: out[k] for k in ("kernel_us", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU") if k in out})
