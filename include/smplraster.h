@@ -267,24 +267,27 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
  * the backward: [+-1 / sum_c exp(score_c), sign = the background clip's gate | background score | q_t softmax_t |
  * label bits].  seg may be NULL: the (B, W, W, 32) scores then never leave the chip (295 KB per mesh not written,
  * and not read twice by the loss kernels); arg and rec are written as by smplr_seg_fwd.  P must be 31.
- *   smplr_seg_raster_loss        = smplr_seg_raster with the epilogue (after smplr_seg_bin)
- *   smplr_skin_vis_seg_loss_fwd  = smplr_skin_vis_seg_fwd with the epilogue (what the decoder runs when it is given a
- *                                  loss); verts, proj, mask, seg may each be NULL
+ *   smplr_seg_raster_ex          = smplr_seg_raster with optional extras (after smplr_seg_bin): loss != NULL adds the
+ *                                  epilogue (then labels and stats are required and seg may be NULL); vmax != NULL
+ *                                  (B, W, W) receives each pixel's largest part score - the hint smplr_silh_fwd_hint
+ *                                  takes; with loss = vmax = NULL it IS smplr_seg_raster
+ *   smplr_skin_vis_seg_fwd_ex    = smplr_skin_vis_seg_fwd with the same extras (what the decoder runs when it is
+ *                                  given a loss and / or renders the silhouette too); verts, proj, mask may each be NULL
  *   smplr_seg_loss_bwd           = smplr_seg_bwd fed with dloss (B, W*W) and stats instead of dseg: a lane rebuilds its
  *                                  channel's d loss / d score = A (delta_ct - softmax_c) - g_background from its own
  *                                  recomputed score, A = dloss q_t softmax_t (20 B per pixel read instead of 128);
  *                                  same workspace, dproj = NULL and deterministic as smplr_seg_bwd.
  * The softmax takes no max shift (scores lie in [0, 1]) and uses v_exp_f32; against smplr_focal_fwd/bwd on the written
- * scores the loss agrees to ~1e-6 relative (tests/test_gpu_loss_fused.py).                                       */
-int smplr_seg_raster_loss(int B, int W, int P, int K, const void *workspace, const float *rec,
-                          const int32_t *labels, const float *class_w, float gamma, float *seg, int16_t *arg,
-                          float *loss, float *stats, void *stream);
-int smplr_skin_vis_seg_loss_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
-                                int x_stride, int B, int V, int W, int grid_wh, int ref_compat,
-                                const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,
-                                const int32_t *labels, const float *class_w, float gamma, float *verts, float *proj,
-                                float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, float *loss,
-                                float *stats, void *stream);
+ * scores the loss agrees to ~1e-5 relative (tests/test_gpu_loss_fused.py).                                       */
+int smplr_seg_raster_ex(int B, int W, int P, int K, const void *workspace, const float *rec,
+                        const int32_t *labels, const float *class_w, float gamma, float *seg, int16_t *arg,
+                        float *loss, float *stats, float *vmax, void *stream);
+int smplr_skin_vis_seg_fwd_ex(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
+                              int x_stride, int B, int V, int W, int grid_wh, int ref_compat,
+                              const int32_t *part_pos, const int32_t *part_off, int P, int K, void *workspace,
+                              const int32_t *labels, const float *class_w, float gamma, float *verts, float *proj,
+                              float *mask, float *seg, int16_t *arg, float *rec, int16_t *vslot, float *loss,
+                              float *stats, float *vmax, void *stream);
 int smplr_seg_loss_bwd(const float *dloss, const float *stats, const int16_t *arg, const float *rec, int B, int VP,
                        int W, int P, int K, float *dproj, void *workspace, int deterministic, void *stream);
 
@@ -294,6 +297,12 @@ int smplr_seg_loss_bwd(const float *dloss, const float *stats, const int16_t *ar
 size_t smplr_silh_workspace(int B, int VP, int W);
 int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg,
                    void *workspace, void *stream);
+/* The same with a per-pixel hint (B, W, W), laid out as the output: a score exp(-x), x >= the distance from the pixel
+ * to SOME vertex - smplr_seg_raster_ex's vmax of the same meshes at the same W.  It only bounds the exact search
+ * (W <= 48: the pixel-per-lane kernel; ignored otherwise): outputs are bit for bit those of smplr_silh_fwd.  0 = no hint
+ * for that pixel; hint = NULL is smplr_silh_fwd.                                                                 */
+int smplr_silh_fwd_hint(const float *proj, const float *hint, int B, int VP, int W, float *silh, int32_t *arg,
+                        void *workspace, void *stream);
 int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg,
                    const float *proj, int B, int VP, int W, float *dproj, int deterministic, void *stream);
 

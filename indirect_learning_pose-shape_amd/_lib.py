@@ -61,12 +61,13 @@ SIGNATURES = {
     "smplr_seg_bwd_nsplit": (c_int, [I, I]),
     "smplr_seg_bwd_workspace": (c_size_t, [I, I]),
     "smplr_seg_bwd": (c_int, [P, P, P, I, I, I, I, I, P, P, I, P]),
-    "smplr_seg_raster_loss": (c_int, [I, I, I, I, P, P, P, P, c_float, P, P, P, P, P]),
-    "smplr_skin_vis_seg_loss_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P, I, I, P, P, P, c_float, P, P, P, P, P, P,
-                                            P, P, P, P]),
+    "smplr_seg_raster_ex": (c_int, [I, I, I, I, P, P, P, P, c_float, P, P, P, P, P, P]),
+    "smplr_skin_vis_seg_fwd_ex": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P, I, I, P, P, P, c_float, P, P, P, P, P, P,
+                                          P, P, P, P, P]),
     "smplr_seg_loss_bwd": (c_int, [P, P, P, P, I, I, I, I, I, P, P, I, P]),
     "smplr_silh_workspace": (c_size_t, [I, I, I]),
     "smplr_silh_fwd": (c_int, [P, I, I, I, P, P, P, P]),
+    "smplr_silh_fwd_hint": (c_int, [P, P, I, I, I, P, P, P, P]),
     "smplr_silh_bwd": (c_int, [P, P, P, P, I, I, I, P, I, P]),
     "smplr_focal_fwd": (c_int, [P, P, P, P, c_float, c_longlong, I, P, P, P]),
     "smplr_focal_bwd": (c_int, [P, P, P, P, c_float, P, c_longlong, I, P, P]),

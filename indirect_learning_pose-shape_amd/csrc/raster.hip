@@ -598,6 +598,13 @@ __device__ __forceinline__ float sum8_dpp(float v) {
   return v;
 }
 
+__device__ __forceinline__ float max8_dpp(float v) {
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+  return v;
+}
+
 // Block = 256 pixels of one mesh x 4 part ranges = 16 waves: wave (g, w) evaluates the parts of range g
 // for pixels [64w, 64w+64) of the tile.  What bounds this kernel at small batch is the per-wave
 // dependent chain (LDS reads -> VALU -> exp -> LDS, part after part), so the parts are spread over 4
@@ -612,7 +619,10 @@ __device__ __forceinline__ float sum8_dpp(float v) {
 // need not be written at all (seg = NULL): the backward (seg_bwd_kernel<.., LOSS>) rebuilds d loss / d score of every
 // channel from 16 bytes per pixel left here (`stats`: 1 / sum exp(score), sign = the clip's gate | background score |
 // q_t softmax_t | label) instead of reading a 128-B row of dseg.  Scores lie in [0, 1]: the softmax needs no max shift.
-struct LossOut { const int *labels; const float *class_w; float gamma; float *loss; float4 *stats; };
+// vmax (optional, with or without the loss): per pixel the largest of its 31 part scores, as the output lies - for the
+// silhouette rasteriser an upper bound of the distance to the nearest vertex (-log of it: a score is exp(-m d), m >= 1),
+// which spares it its own search for one (smplr_silh_fwd_hint).
+struct LossOut { const int *labels; const float *class_w; float gamma; float *loss; float4 *stats; float *vmax; };
 
 template <bool LOSS>
 __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
@@ -854,6 +864,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       }
     }
     const float sum = sum8_dpp((v[0] + v[1]) + (v[2] + v[3]));   // over the pixel's parts (all lanes take part)
+    float vmx = 0.0f;
+    if (lo.vmax) vmx = max8_dpp(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));   // (block-uniform; channel 0 holds 0 here)
     if (c4 == 0) {
       v[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
       a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
@@ -878,6 +890,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     if (qq < npix && c4 < C) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
       const unsigned po = (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68); mesh base + 32-bit offset
+      if (lo.vmax && c4 == 0) lo.vmax[(size_t)n * npix + po] = vmx;
       if (LOSS && c4 == 0) {
         lo.loss[(size_t)n * npix + po] = ls;
         lo.stats[(size_t)n * npix + po] = make_float4(a[0] ? inv : -inv, v[0], k1, __int_as_float(lab[it]));
@@ -1632,8 +1645,14 @@ static SpxLds silh_px_layout(int VP, int W) {
   return L;
 }
 
+// hint (optional, (B, W, W) as the output lies): per pixel a score exp(-x) with x >= the distance to SOME vertex - the
+// 31-part rasteriser's largest part score of the pixel (raster_fwd_kernel's vmax: exp(-m d) of a real vertex, m >= 1).
+// A pixel whose own cell is empty then takes -log(hint) as its search radius instead of walking the rows for the
+// nearest occupied cell (step (2): a third of this kernel's time); the candidates of step (3) are a superset of
+// those the nearest vertex' cell belongs to either way, so the result is the same bit for bit.
 __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__ proj, int VP, int W, SpxLds L,
-                                                       float *__restrict__ out, int *__restrict__ arg_out) {
+                                                       float *__restrict__ out, int *__restrict__ arg_out,
+                                                       const float *__restrict__ hint) {
   extern __shared__ __attribute__((aligned(16))) int s_cnt[];
   __shared__ int s_next_tile;
   if (threadIdx.x == 0) s_next_tile = 0;             // (ordered by the binning's barriers)
@@ -1761,6 +1780,8 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
     unsigned long long best = own[r * WP + c];             // (d^2 bits << 32) | vertex index; ~0: own cell empty
     unsigned long long rows = 0ull;
     float lim = -1.0f;                                      // squared search radius (< 0: nothing to search)
+    float hs = 0.0f;                                        // the hint's score for this pixel (0: none)
+    if (hint) hs = hint[((size_t)n * W + (W - 1 - r)) * W + c];
     if (best != ~0ull) {
       // (1) own cell occupied: other cells matter only if the nearest own vertex is farther than half a cell
       const float d2 = __uint_as_float((unsigned int)(best >> 32));
@@ -1768,6 +1789,11 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
         lim = d2 * 1.000001f;
         rows = 7ull << (cy - 1);                            // rows cy - 1 .. cy + 1 (cy >= SM)
       }
+    } else if (hs > 0.0f) {
+      // (2') some vertex lies within -log(hs) of the pixel (+ 1e-3 for the approximate exp / log): every row in reach
+      const float b = 1e-3f - __logf(hs);
+      lim = b * b * 1.0001f;
+      rows = ~0ull;
     } else {
       // (2) nearest occupied cell + the rows that can hold a candidate
       int best2 = 1 << 30, q0 = -1;
@@ -2045,7 +2071,7 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
   SMPLR_REQUIRE(!with_loss || (P == 31 && lo.gamma >= 0.0f),
                 "%s: the loss epilogue is the 32-class head's (P = 31, gamma >= 0): P=%d gamma=%g", fn, P, (double)lo.gamma);
   if (B == 0) return 0;
-  SMPLR_REQUIRE(workspace && rec && (seg || with_loss) && arg, "%s: null pointer", fn);
+  SMPLR_REQUIRE(workspace && rec && (seg || with_loss) && arg, "%s: null pointer (seg may be NULL only with a loss)", fn);
   SMPLR_REQUIRE(!with_loss || (lo.labels && lo.stats), "%s: the loss epilogue needs labels and stats", fn);
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
@@ -2121,27 +2147,27 @@ int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const fl
   return seg_raster_impl("smplr_skin_vis_seg_fwd", B, W, P, K, workspace, rec, seg, arg, stream);
 }
 
-int smplr_seg_raster_loss(int B, int W, int P, int K, const void *workspace, const float *rec, const int32_t *labels,
-                          const float *class_w, float gamma, float *seg, int16_t *arg, float *loss, float *stats,
-                          void *stream) {
-  SMPLR_REQUIRE(B <= 0 || loss, "smplr_seg_raster_loss: null loss");
-  return smplr::seg_raster_impl("smplr_seg_raster_loss", B, W, P, K, workspace, rec, seg, arg, stream,
-                                smplr::LossOut{labels, class_w, gamma, loss, reinterpret_cast<float4 *>(stats)});
+int smplr_seg_raster_ex(int B, int W, int P, int K, const void *workspace, const float *rec, const int32_t *labels,
+                        const float *class_w, float gamma, float *seg, int16_t *arg, float *loss, float *stats,
+                        float *vmax, void *stream) {
+  return smplr::seg_raster_impl("smplr_seg_raster_ex", B, W, P, K, workspace, rec, seg, arg, stream,
+                                smplr::LossOut{labels, class_w, gamma, loss, reinterpret_cast<float4 *>(stats), vmax});
 }
 
-int smplr_skin_vis_seg_loss_fwd(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
-                                int x_stride, int B, int V, int W, int grid_wh, int ref_compat, const int32_t *part_pos,
-                                const int32_t *part_off, int P, int K, void *workspace, const int32_t *labels,
-                                const float *class_w, float gamma, float *verts, float *proj, float *mask, float *seg,
-                                int16_t *arg, float *rec, int16_t *vslot, float *loss, float *stats, void *stream) {
+int smplr_skin_vis_seg_fwd_ex(const float *v_posed, const float *lbs_top4, const float *A, const float *cam,
+                              int x_stride, int B, int V, int W, int grid_wh, int ref_compat, const int32_t *part_pos,
+                              const int32_t *part_off, int P, int K, void *workspace, const int32_t *labels,
+                              const float *class_w, float gamma, float *verts, float *proj, float *mask, float *seg,
+                              int16_t *arg, float *rec, int16_t *vslot, float *loss, float *stats, float *vmax,
+                              void *stream) {
   using namespace smplr;
-  SMPLR_REQUIRE(B <= 0 || (v_posed && lbs_top4 && A && cam && loss), "smplr_skin_vis_seg_loss_fwd: null pointer");
+  SMPLR_REQUIRE(B <= 0 || (v_posed && lbs_top4 && A && cam), "smplr_skin_vis_seg_fwd_ex: null pointer");
   const SkinIn sk{v_posed, lbs_top4, A, cam, x_stride, verts, proj};
-  int rc = seg_bin_impl("smplr_skin_vis_seg_loss_fwd", proj, mask, true, grid_wh, ref_compat, B, V, W, part_pos, part_off,
+  int rc = seg_bin_impl("smplr_skin_vis_seg_fwd_ex", proj, mask, true, grid_wh, ref_compat, B, V, W, part_pos, part_off,
                         P, K, workspace, rec, vslot, stream, sk);
   if (rc) return rc;
-  return seg_raster_impl("smplr_skin_vis_seg_loss_fwd", B, W, P, K, workspace, rec, seg, arg, stream,
-                         LossOut{labels, class_w, gamma, loss, reinterpret_cast<float4 *>(stats)});
+  return seg_raster_impl("smplr_skin_vis_seg_fwd_ex", B, W, P, K, workspace, rec, seg, arg, stream,
+                         LossOut{labels, class_w, gamma, loss, reinterpret_cast<float4 *>(stats), vmax});
 }
 
 int smplr_seg_bwd_nsplit(int B, int W) {
@@ -2217,6 +2243,11 @@ size_t smplr_silh_workspace(int B, int VP, int W) {
 
 int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t *arg, void *workspace,
                    void *stream) {
+  return smplr_silh_fwd_hint(proj, nullptr, B, VP, W, silh, arg, workspace, stream);
+}
+
+int smplr_silh_fwd_hint(const float *proj, const float *hint, int B, int VP, int W, float *silh, int32_t *arg,
+                        void *workspace, void *stream) {
   using namespace smplr;
   SMPLR_REQUIRE(B >= 0 && VP > 0 && W > 0 && W <= 1024, "smplr_silh_fwd: bad sizes B=%d VP=%d W=%d", B, VP, W);
   if (B == 0) return 0;
@@ -2227,7 +2258,7 @@ int smplr_silh_fwd(const float *proj, int B, int VP, int W, float *silh, int32_t
     const int nsplit = B >= 256 ? 1 : (B >= 128 ? 2 : 4);      // one workgroup per CU (256 CUs)
     int rc = set_lds_attr(reinterpret_cast<const void *>(silh_px_kernel), L.total);
     if (rc) return rc;
-    hipLaunchKernelGGL(silh_px_kernel, dim3(B, nsplit), dim3(SF_T), L.total, st, proj, VP, W, L, silh, arg);
+    hipLaunchKernelGGL(silh_px_kernel, dim3(B, nsplit), dim3(SF_T), L.total, st, proj, VP, W, L, silh, arg, hint);
     SMPLR_LAUNCH_CHECK("smplr_silh_fwd");
     return 0;
   }

@@ -52,7 +52,7 @@ def softmax_focal_loss(gamma=2.0, weight_classes=False):
         from . import ops
         w = class_weights(scores.device)[: scores.shape[-1]].contiguous() if weight_classes else None
         return ops.SoftmaxFocalFn.apply(scores, y_true, w, float(gamma))
-    # what `SMPLDecoder(loss=...)` reads to run this head inside the rasteriser instead (smplr_skin_vis_seg_loss_fwd)
+    # what `SMPLDecoder(loss=...)` reads to run this head inside the rasteriser instead (smplr_skin_vis_seg_fwd_ex)
     loss.gamma, loss.weight_classes = float(gamma), bool(weight_classes)
     return loss
 

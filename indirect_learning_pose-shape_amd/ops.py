@@ -355,42 +355,57 @@ def _skin_vis_seg_fwd(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, grid_
 
 
 @on_device
-def _skin_vis_seg_loss_fwd(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, labels, class_w, gamma, grid_wh=64,
-                           ref_compat=True, verts=None, proj=None, mask=None, seg=None, arg=None, rec=None, vslot=None,
-                           loss=None, stats=None):
-    """_skin_vis_seg_fwd with the loss head as the rasteriser's epilogue (smplr_skin_vis_seg_loss_fwd): labels (B,W,W)
-    int32 -> loss (B, W*W), stats (B, W*W, 4); verts / proj / mask / seg are written only where a tensor is given."""
+def _skin_vis_seg_fwd_ex(v_posed, A, c: SMPLConstants, cam, W, pt: PartTable, labels=None, class_w=None, gamma=0.0,
+                         grid_wh=64, ref_compat=True, verts=None, proj=None, mask=None, seg=None, arg=None, rec=None,
+                         vslot=None, loss=None, stats=None, vmax=None):
+    """_skin_vis_seg_fwd with optional extras (smplr_skin_vis_seg_fwd_ex): with `labels` (B,W,W) int32 the loss head
+    runs as the rasteriser's epilogue -> loss (B, W*W), stats (B, W*W, 4); `vmax` (B,W,W) receives each pixel's largest
+    part score (the silhouette rasteriser's hint); verts / proj / mask / seg are written only where a tensor is given
+    (seg may be omitted only with labels)."""
     lib = _lib.load()
     B, V = v_posed.shape[0], c.V
     if c.lbs_top4 is None or pt.VP != V or not lib.smplr_skin_vis_seg_fits(V, int(W), int(grid_wh)):
-        raise RuntimeError("_skin_vis_seg_loss_fwd: needs sparse skinning weights, vertex_sampling = 1 and sizes that fit "
+        raise RuntimeError("_skin_vis_seg_fwd_ex: needs sparse skinning weights, vertex_sampling = 1 and sizes that fit "
                            "the binning workgroup's LDS (smplr_skin_vis_seg_fits)")
     ws = _workspace(lib.smplr_seg_workspace(B, V, W, pt.P, pt.K), v_posed)
     if arg is None:
         arg = _empty((B, W, W, 32), v_posed, torch.int16)
     if rec is None:
         rec = _empty((B, lib.smplr_seg_slots(pt.P, pt.K), 4), v_posed)
-    loss = _empty((B, W * W), v_posed) if loss is None else loss
-    stats = _empty((B, W * W, 4), v_posed) if stats is None else stats
-    check(lib.smplr_skin_vis_seg_loss_fwd(ptr(v_posed), ptr(c.lbs_top4), ptr(A), ptr(cam), cam.shape[1], B, V, W,
-                                          int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos), ptr(pt.part_off),
-                                          pt.P, pt.K, ptr(ws), ptr(labels), ptr(class_w), float(gamma), ptr(verts),
-                                          ptr(proj), ptr(mask), ptr(seg), ptr(arg), ptr(rec), ptr(vslot), ptr(loss),
-                                          ptr(stats), stream()), "smplr_skin_vis_seg_loss_fwd")
+    if labels is not None:
+        loss = _empty((B, W * W), v_posed) if loss is None else loss
+        stats = _empty((B, W * W, 4), v_posed) if stats is None else stats
+    else:
+        loss = stats = None
+    check(lib.smplr_skin_vis_seg_fwd_ex(ptr(v_posed), ptr(c.lbs_top4), ptr(A), ptr(cam), cam.shape[1], B, V, W,
+                                        int(grid_wh), 1 if ref_compat else 0, ptr(pt.part_pos), ptr(pt.part_off),
+                                        pt.P, pt.K, ptr(ws), ptr(labels), ptr(class_w), float(gamma), ptr(verts),
+                                        ptr(proj), ptr(mask), ptr(seg), ptr(arg), ptr(rec), ptr(vslot), ptr(loss),
+                                        ptr(stats), ptr(vmax), stream()), "smplr_skin_vis_seg_fwd_ex")
     return loss, stats, arg, rec
 
 
 @on_device
-def _seg_raster_loss(ws, rec, B, W, pt: PartTable, labels, class_w, gamma, seg=None, arg=None, loss=None, stats=None):
-    """Stage 2 with the loss epilogue (smplr_seg_raster_loss) over a binned workspace -> loss, stats, arg."""
+def _seg_raster_ex(ws, rec, B, W, pt: PartTable, labels=None, class_w=None, gamma=0.0, seg=None, arg=None, loss=None,
+                   stats=None, vmax=None):
+    """Stage 2 with optional extras (smplr_seg_raster_ex) over a binned workspace -> loss, stats, arg (loss epilogue with
+    `labels`; `vmax`: per-pixel largest part score)."""
     lib = _lib.load()
     if arg is None:
         arg = _empty((B, W, W, 32), rec, torch.int16)
-    loss = _empty((B, W * W), rec) if loss is None else loss
-    stats = _empty((B, W * W, 4), rec) if stats is None else stats
-    check(lib.smplr_seg_raster_loss(B, W, pt.P, pt.K, ptr(ws), ptr(rec), ptr(labels), ptr(class_w), float(gamma),
-                                    ptr(seg), ptr(arg), ptr(loss), ptr(stats), stream()), "smplr_seg_raster_loss")
+    if labels is not None:
+        loss = _empty((B, W * W), rec) if loss is None else loss
+        stats = _empty((B, W * W, 4), rec) if stats is None else stats
+    else:
+        loss = stats = None
+    check(lib.smplr_seg_raster_ex(B, W, pt.P, pt.K, ptr(ws), ptr(rec), ptr(labels), ptr(class_w), float(gamma),
+                                  ptr(seg), ptr(arg), ptr(loss), ptr(stats), ptr(vmax), stream()), "smplr_seg_raster_ex")
     return loss, stats, arg
+
+
+def _seg_raster_loss(ws, rec, B, W, pt, labels, class_w, gamma, seg=None, arg=None, loss=None, stats=None):
+    """The loss-epilogue form of _seg_raster_ex (kept as a name of its own: tests, tools)."""
+    return _seg_raster_ex(ws, rec, B, W, pt, labels, class_w, gamma, seg=seg, arg=arg, loss=loss, stats=stats)
 
 
 @on_device
@@ -459,7 +474,9 @@ def argmin_vertices(arg, rec):
 
 
 @on_device
-def _silh_fwd(proj, W, out=None):
+def _silh_fwd(proj, W, out=None, hint=None):
+    """hint (B,W,W), optional: the 31-part rasteriser's per-pixel largest score of the same meshes at the same W
+    (_seg_raster_ex(vmax=)): bounds the exact search, same outputs bit for bit (smplr_silh_fwd_hint)."""
     lib = _lib.load()
     B, VP = proj.shape[0], proj.shape[1]
     if out is not None:
@@ -468,7 +485,8 @@ def _silh_fwd(proj, W, out=None):
         silh = _empty((B, W, W, 2), proj)
         arg = _empty((B, W, W), proj, torch.int32)
     ws = _workspace(lib.smplr_silh_workspace(B, VP, W), proj)
-    check(lib.smplr_silh_fwd(ptr(proj), B, VP, W, ptr(silh), ptr(arg), ptr(ws), stream()), "smplr_silh_fwd")
+    check(lib.smplr_silh_fwd_hint(ptr(proj), ptr(hint), B, VP, W, ptr(silh), ptr(arg), ptr(ws), stream()),
+          "smplr_silh_fwd_hint")
     return silh, arg
 
 
@@ -933,6 +951,10 @@ class DecoderFn(torch.autograd.Function):
             silh, sarg = _empty((B, Ws, Ws, 2), x), _empty((B, Ws, Ws), x, torch.int32)
         else:
             silh = sarg = None
+        # both heads at one resolution: the part rasteriser hands the silhouette rasteriser each pixel's largest part
+        # score - an upper bound of the distance to the nearest vertex that spares it its own search for one
+        vmax = _empty((B, W, W), x) if (with_silh and opts.seg and Ws == W and pt.P == 31
+                                        and os.environ.get("SMPLR_SILH_HINT", "1") != "0") else None
 
         # the binning workgroups skin their own vertices (one launch less) when the skinning rows are sparse, every
         # vertex is rasterised and the mesh fits the binning workgroup's LDS; SMPLR_FUSE_SKIN=0 keeps the two calls
@@ -949,11 +971,12 @@ class DecoderFn(torch.autograd.Function):
             else:
                 coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
                 _blend_fwd(coef, consts, n, out=v_posed[lo:hi])
-            if fuse_skin and loss_spec is not None:
-                _skin_vis_seg_loss_fwd(
-                    v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, labels[lo:hi], class_w, gamma, grid_wh, ref_compat,
+            if fuse_skin and (loss_spec is not None or vmax is not None):
+                _skin_vis_seg_fwd_ex(
+                    v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, sl(labels, lo, hi), class_w, gamma, grid_wh, ref_compat,
                     verts=sl(verts, lo, hi), proj=sl(proj, lo, hi), mask=sl(mask, lo, hi), seg=sl(seg, lo, hi),
-                    arg=arg[lo:hi], rec=rec[lo:hi], vslot=vslot[lo:hi], loss=loss[lo:hi], stats=stats[lo:hi])
+                    arg=arg[lo:hi], rec=rec[lo:hi], vslot=vslot[lo:hi], loss=sl(loss, lo, hi), stats=sl(stats, lo, hi),
+                    vmax=sl(vmax, lo, hi))
             elif fuse_skin:
                 _skin_vis_seg_opt(v_posed[lo:hi], A[lo:hi], consts, xs, W, pt, grid_wh, ref_compat,
                                   sl(verts, lo, hi), sl(proj, lo, hi), sl(mask, lo, hi), seg[lo:hi], arg[lo:hi],
@@ -965,15 +988,15 @@ class DecoderFn(torch.autograd.Function):
                           out=(sl(verts, lo, hi), pj))
                 if opts.seg:
                     mk = mask[lo:hi] if mask is not None else _empty((n, VP), x)
-                    if loss_spec is not None:
+                    if loss_spec is not None or vmax is not None:
                         ws_, _ = _seg_bin(pj, mk, W, pt, grid_wh, ref_compat, rec=rec[lo:hi], vslot=vslot[lo:hi])
-                        _seg_raster_loss(ws_, rec[lo:hi], n, W, pt, labels[lo:hi], class_w, gamma, seg=sl(seg, lo, hi),
-                                         arg=arg[lo:hi], loss=loss[lo:hi], stats=stats[lo:hi])
+                        _seg_raster_ex(ws_, rec[lo:hi], n, W, pt, sl(labels, lo, hi), class_w, gamma, seg=sl(seg, lo, hi),
+                                       arg=arg[lo:hi], loss=sl(loss, lo, hi), stats=sl(stats, lo, hi), vmax=sl(vmax, lo, hi))
                     else:
                         _vis_seg_fwd(pj, W, pt, grid_wh, ref_compat,
                                      out=(mk, seg[lo:hi], arg[lo:hi], rec[lo:hi]), vslot=vslot[lo:hi])
             if with_silh:
-                _silh_fwd(proj[lo:hi], Ws, out=(silh[lo:hi], sarg[lo:hi]))
+                _silh_fwd(proj[lo:hi], Ws, out=(silh[lo:hi], sarg[lo:hi]), hint=sl(vmax, lo, hi))
 
         bounds = _chunk_bounds(B, nchunk)
         if B > 0:

@@ -1,5 +1,5 @@
 """The loss head fused into the rasteriser (model.py:119-120 + focal_loss.py:10-46):
-smplr_seg_raster_loss / smplr_skin_vis_seg_loss_fwd / smplr_seg_loss_bwd against the float64 oracle
+smplr_seg_raster_ex / smplr_skin_vis_seg_fwd_ex / smplr_seg_loss_bwd against the float64 oracle
 (np_oracle.categorical_focal_loss on np_oracle.projects_to_seg; gradients: torch_oracle autograd) and against the
 unfused HIP path (scores written out, smplr_focal_fwd/bwd, smplr_seg_bwd).
 
@@ -161,11 +161,11 @@ def test_fused_loss_argument_errors(layer):
     lib = _lib.load()
     # P != 31 or a negative gamma are refused before any launch
     one = torch.zeros(4, device=dev())
-    rc = lib.smplr_seg_raster_loss(1, 48, 17, 100, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, 2.0, None,
-                                   _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None)
+    rc = lib.smplr_seg_raster_ex(1, 48, 17, 100, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, 2.0, None,
+                                 _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, None)
     assert rc == -1 and b"32-class" in lib.smplr_last_error()
-    rc = lib.smplr_seg_raster_loss(1, 48, 31, 6879, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, -1.0, None,
-                                   _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None)
+    rc = lib.smplr_seg_raster_ex(1, 48, 31, 6879, _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, -1.0, None,
+                                 _lib.ptr(one), _lib.ptr(one), _lib.ptr(one), None, None)
     assert rc == -1 and b"gamma" in lib.smplr_last_error()
     rc = lib.smplr_seg_loss_bwd(None, None, None, None, 1, 6890, 48, 31, 6879, None, None, 0, None)
     assert rc == -1 and b"dloss" in lib.smplr_last_error()
@@ -260,3 +260,25 @@ def test_trainer_fused_loss_equals_unfused(smpl_model):
         assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12
     l3 = tr.step(images, None, silh_labels)                        # silhouettes_model.fit's step
     assert np.isfinite(float(l3))
+
+
+@pytest.mark.parametrize("B", [3, 128])
+def test_silhouette_hint_changes_nothing(layer, B):
+    """smplr_seg_raster_ex's vmax = each pixel's largest part score, handed to smplr_silh_fwd_hint as a bound of the
+    distance to the nearest vertex: silhouette and arg-max vertex are bit for bit those of smplr_silh_fwd."""
+    from ilps_amd import ops
+    W = 48
+    proj, mask = _proj_mask(layer, B, W, seed=40 + B)
+    pt = ops.get_part_table(1, proj.device, 6890)
+    ws, rec = ops._seg_bin(proj, mask, W, pt)
+    seg = torch.empty(B, W, W, 32, device=dev())
+    vmax = torch.empty(B, W, W, device=dev())
+    ops._seg_raster_ex(ws, rec, B, W, pt, seg=seg, vmax=vmax)
+    assert torch.equal(vmax, seg[..., 1:].max(-1).values)
+    s0, a0 = ops._silh_fwd(proj, W)
+    s1, a1 = ops._silh_fwd(proj, W, hint=vmax)
+    assert torch.equal(s0, s1) and torch.equal(a0, a1)
+    # a hint of zeros (no information) and a far-too-generous one (every vertex in reach) change nothing either
+    s2, a2 = ops._silh_fwd(proj, W, hint=torch.zeros_like(vmax))
+    s3, a3 = ops._silh_fwd(proj, W, hint=torch.full_like(vmax, 1e-30))
+    assert torch.equal(s0, s2) and torch.equal(a0, a2) and torch.equal(s0, s3) and torch.equal(a0, a3)
