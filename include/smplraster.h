@@ -264,8 +264,8 @@ int smplr_seg_bwd(const float *dseg, const int16_t *arg, const float *rec,
  * focal loss at an INTEGER class map are its epilogue: labels (B, W, W) int32 as the output lies (rows flipped; an id
  * outside [0, 32) contributes no loss and no gradient, as in smplr_focal_fwd), class_w (32) or NULL, gamma >= 0
  * -> loss (B, W*W) per pixel (the value smplr_focal_fwd would return on the scores) and stats (B, W*W, 4) fp32 for
- * the backward: [+-1 / sum_c exp(score_c), sign = the background clip's gate | background score | q_t softmax_t |
- * label bits].  seg may be NULL: the (B, W, W, 32) scores then never leave the chip (295 KB per mesh not written,
+ * the backward: [k / sum_c exp(score_c) | k x (delta_0t - softmax_0 where the background clip's gate is open, else 0) |
+ * k = q_t softmax_t | label bits].  seg may be NULL: the (B, W, W, 32) scores then never leave the chip (295 KB per mesh not written,
  * and not read twice by the loss kernels); arg and rec are written as by smplr_seg_fwd.  P must be 31.
  *   smplr_seg_raster_ex          = smplr_seg_raster with optional extras (after smplr_seg_bin): loss != NULL adds the
  *                                  epilogue (then labels and stats are required and seg may be NULL); vmax != NULL

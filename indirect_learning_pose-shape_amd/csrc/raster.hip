@@ -617,8 +617,9 @@ __device__ __forceinline__ float max8_dpp(float v) {
 // class map): a pixel's 32 raw scores sit in 8 adjacent lanes at write-out time, so its softmax denominator, the
 // labelled class' probability and the per-pixel loss cost two 8-lane tree sums - and the (B, W, W, 32) score tensor
 // need not be written at all (seg = NULL): the backward (seg_bwd_kernel<.., LOSS>) rebuilds d loss / d score of every
-// channel from 16 bytes per pixel left here (`stats`: 1 / sum exp(score), sign = the clip's gate | background score |
-// q_t softmax_t | label) instead of reading a 128-B row of dseg.  Scores lie in [0, 1]: the softmax needs no max shift.
+// channel from 16 bytes per pixel left here (`stats`, k = q_t softmax_t: k / sum exp(score) | k x the background's share
+// (delta_0t - softmax_0 where the clip's gate is open, else 0) | k | label) instead of reading a 128-B row of dseg.
+// Scores lie in [0, 1]: the softmax needs no max shift.
 // vmax (optional, with or without the loss): per pixel the largest of its 31 part scores, as the output lies - for the
 // silhouette rasteriser an upper bound of the distance to the nearest vertex (-log of it: a score is exp(-m d), m >= 1),
 // which spares it its own search for one (smplr_silh_fwd_hint).
@@ -871,21 +872,26 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
     }
     const int qq = tile * RTS + pl;
-    float ls = 0.0f, inv = 0.0f, k1 = 0.0f;
+    float ls = 0.0f, inv = 0.0f, k1 = 0.0f, gbu = 0.0f;
     if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
       const float den = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
       const int t = lab[it];
       const float vt = (t & 2) ? ((t & 1) ? v[3] : v[2]) : ((t & 1) ? v[1] : v[0]);
       const float st = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);   // the labelled class' score in all 8 lanes (+ exact zeros)
-      inv = 1.0f / den;
+      // (v_rcp_f32 / v_log_f32: 1 ulp and ~1e-7 absolute in log2 on p in [1e-7, 1) - far inside the loss head's 1e-4
+      // bar - where the IEEE division and logf() were a fifth of this phase's instructions)
+      inv = __builtin_amdgcn_rcpf(den);
       const float sm = __expf(st) * inv;
       const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
       const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
-      const float om = 1.0f - p, lg = logf(p), w = wlab[it];
-      ls = (unsigned)t < 32u ? pow_gamma(om, lo.gamma) * ((-lg) * w) : 0.0f;     // :18, :41, :43-44
+      const float om = 1.0f - p, lg = __logf(p), w = wlab[it];
+      const float pg = pow_gamma(om, lo.gamma);
+      ls = (unsigned)t < 32u ? pg * ((-lg) * w) : 0.0f;                          // :18, :41, :43-44
       // d loss / d softmax_t (the clip passes gradient on [eps, 1 - eps] only) x softmax_t: with it
       // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
-      k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pow_gamma(om, lo.gamma) / p)) * sm : 0.0f;
+      k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
+      // what the background contributes to every channel's gradient where the clip's gate is open, per unit of k1
+      gbu = a[0] ? ((t == 0 ? 1.0f : 0.0f) - __expf(v[0]) * inv) : 0.0f;         // (lane c4 == 0: v[0] = background)
     }
     if (qq < npix && c4 < C) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       if (lo.vmax && c4 == 0) lo.vmax[(size_t)n * npix + po] = vmx;
       if (LOSS && c4 == 0) {
         lo.loss[(size_t)n * npix + po] = ls;
-        lo.stats[(size_t)n * npix + po] = make_float4(a[0] ? inv : -inv, v[0], k1, __int_as_float(lab[it]));
+        lo.stats[(size_t)n * npix + po] = make_float4(k1 * inv, k1 * gbu, k1, __int_as_float(lab[it]));
       }
       float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
       if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
@@ -1059,9 +1065,9 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
 // channel is rebuilt per pixel from what the forward's loss epilogue left (raster_fwd_kernel<true>),
 //   g_c = A (delta_ct - softmax_c) - g_background,   A = dloss q_t softmax_t,   softmax_c = exp(score_c) / sum exp,
 // with score_c the lane's own recomputed score: every lane of a pixel's 32-lane group reads the same 16 B of `stats`
-// (+- 1 / sum exp with the clip's gate as its sign | background score | q_t softmax_t | label) and 4 B of dloss - one
-// request per group - instead of its own 4 B of a 128-B row of dseg, and folds them at once into the two numbers it
-// needs per pixel, c1 = A delta_ct - g_background and c2 = A / sum exp (g_c = c1 - c2 exp(score_c)).
+// (k / sum exp | k x the background's share | k = q_t softmax_t | label) and 4 B of dloss - one request per group -
+// instead of its own 4 B of a 128-B row of dseg, and folds them at once into the two numbers it needs per pixel,
+// c1 = A delta_ct - g_background and c2 = A / sum exp (g_c = c1 - c2 exp(score_c)).
 struct LossIn { const float *dloss; const float4 *stats; };
 
 // one batch of SB_U pixels of a row: a = arg-min slots, dl = dloss, st = stats of the pixels c0 .. c0 + SB_U - 1
@@ -1075,11 +1081,10 @@ __device__ __forceinline__ void seg_bwd_batch_loss(int c0, int (&a)[SB_U], const
   float4 rv[SB_U];
 #pragma unroll
   for (int u = 0; u < SB_U; ++u) {
-    const float A = dl[u] * st[u].z, inv = fabsf(st[u].x);
-    // what every channel subtracts: the background's gradient A (delta_0t - softmax_0) where the clip's gate is open
-    const float gb0 = A * ((__float_as_int(st[u].w) == 0 ? 1.0f : 0.0f) - __expf(st[u].y) * inv);
-    c1[u] = (__float_as_int(st[u].w) == ch ? A : 0.0f) - (st[u].x > 0.0f ? gb0 : 0.0f);
-    c2[u] = A * inv;
+    // stats = (k / sum exp, k x the background's share, k, label), k = q_t softmax_t: with dl = dloss
+    //   g_c = dl (k delta_ct - k share_0) - dl (k / sum exp) exp(score_c) = c1 - c2 exp(score_c)
+    c1[u] = dl[u] * ((__float_as_int(st[u].w) == ch ? st[u].z : 0.0f) - st[u].y);
+    c2[u] = dl[u] * st[u].x;
     if (!(chok && c0 + u < W)) a[u] = -1;
     if (MW) {
       a[u] -= base;

@@ -80,12 +80,20 @@ def test_fused_loss_stage_parity(layer, part_tables, W, gamma, weighted):
     p64, m64 = proj.cpu().numpy().astype(np.float64), mask.cpu().numpy().astype(np.float64)
     want_b = o.categorical_focal_loss(y, o.softmax_last(o.projects_to_seg(p64, m64, W, ids, off)), gamma, weighted)
     assert np.all(np.abs(got - want_b) <= 2e-3 * np.abs(want_b) + 1e-6)
-    # stats: label bits, background score, sign = the clip's gate
-    st = stats.cpu().numpy()
-    assert np.array_equal(st[..., 3].view(np.int32).reshape(B, W, W), lab.astype(np.int32))
-    assert np.array_equal(st[..., 1].reshape(B, W, W), seg.cpu().numpy()[..., 0])
-    gate = arg.cpu().numpy()[..., 0] == 1
-    assert np.array_equal(st[..., 0].reshape(B, W, W) > 0, gate)
+    # stats = (k / sum exp | k x the background's share | k = q_t softmax_t | label bits): against float64 on the HIP scores
+    st = stats.cpu().numpy().astype(np.float64)
+    assert np.array_equal(stats.cpu().numpy()[..., 3].view(np.int32).reshape(B, W, W), lab.astype(np.int32))
+    s64_ = seg.cpu().numpy().astype(np.float64).reshape(B, W * W, 32)
+    den = np.exp(s64_).sum(-1)
+    smt = np.take_along_axis(np.exp(s64_), lab.reshape(B, -1, 1), 2)[..., 0] / den
+    wt = (w64[lab.reshape(B, -1)] if weighted else 1.0)
+    dpow = gamma * (1 - smt) ** (gamma - 1) if gamma > 0 else 0.0        # d/dx x^gamma at x = 1 - p
+    q = wt * (dpow * np.log(smt) - (1 - smt) ** gamma / smt)               # d loss / d softmax_t (no clip in reach)
+    k = q * smt
+    assert np.allclose(st[..., 2], k, rtol=2e-5, atol=1e-9) and np.allclose(st[..., 0], k / den, rtol=2e-5, atol=1e-10)
+    gate = (arg.cpu().numpy()[..., 0] == 1).reshape(B, -1)
+    share = np.where(gate, (lab.reshape(B, -1) == 0) - np.exp(s64_[..., 0]) / den, 0.0)
+    assert np.allclose(st[..., 1], k * share, rtol=2e-5, atol=1e-9)
     # backward: dproj against float64 autograd through projects_to_seg + softmax + focal loss
     cot = rng.normal(0, 1, (B, W * W))
     dproj = ops._seg_loss_bwd(t(cot), stats, arg, rec, 6890, W, pt, merge=True)
