@@ -188,7 +188,7 @@ def raster_roofline(x, consts, pt, W, stages):
     if os.path.exists(tf) and B == 128 and W == 48:
         try:
             tj = json.load(open(tf))
-            k = tj["kernels"].get("raster_fwd_kernel", {})
+            k = next((v for kn, v in tj["kernels"].items() if kn.startswith("raster_fwd_kernel")), {})
             # the committed counter passes are stamped with the library they were taken on
             out["profile_build_id_matches"] = tj.get("build_id") == _lib.build_id()
             out["traffic"] = k.get("hbm_bytes_per_launch")
@@ -753,7 +753,7 @@ def main():
             if os.path.exists(tfile) and B == 128 and W == 48:
                 try:
                     ks = json.load(open(tfile))["kernels"]
-                    step_ks = [k for k in ks if "pack" not in k and "copy" not in k]
+                    step_ks = [k for k in ks if "pack" not in k and "copy" not in k and not k.startswith("at::")]
                     tot = sum(ks[k].get("hbm_bytes_per_launch", 0) for k in step_ks)
                     gbs = tot / (ms * 1e-3) / 1e9
                     line["step_hbm"] = {"bound": "hbm", "traffic": int(tot), "achieved": round(gbs, 1),

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Copies the summaries of one tools/r03_profile.sh run (gpurun_out/TAG) into profiles/ under the round prefix and
+# rebuilds the JSON files bench.py reads (stamped with the measured library's build id, taken from the run's bench
+# line):  bash tools/collect_profiles_r03.sh TAG [PREFIX]      (e.g. r03a r03)
+TAG=$1; P=${2:-r03}; S=gpurun_out/$TAG; D=profiles
+BID=$(python -c "import json; print(json.load(open('$S/bench.json'))['build_id'])")
+export PROFILE_BUILD_ID=$BID
+cp $S/bench.json $D/${P}_bench.json
+cp $S/eager_kernel_stats.csv $D/${P}_eager_kernel_stats.csv
+cp $S/default_kernel_stats.csv $D/${P}_default_bench_kernel_stats.csv
+cp $S/pmc_step_sq.txt $D/${P}_pmc_step_sq_counters.txt
+cp $S/batch_sweep.txt $D/${P}_batch_sweep.txt
+for V in seg_only fused_loss unfused_loss both_heads silhouette_only; do
+  cp $S/${V}_kernel_stats.csv $D/${P}_${V}_kernel_stats.csv
+  PMC_TRAFFIC_NAME=${P}_traffic_${V}.json python tools/pmc_traffic.py $S/pmc_${V}_1 $S/pmc_${V}_2
+done
+python tools/pmc_traffic.py $S/pmc_step_3 $S/pmc_step_4 $S/pmc_step_5
+python tools/raster_sq.py $S/eager_kernel_stats.csv 1.95,3.25 $S/pmc_step_1 $S/pmc_step_2
+ls $D

@@ -36,7 +36,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import ilps_amd  # noqa: E402,F401
 from ilps_amd import _lib  # noqa: E402
-out["build_id"] = _lib.source_build_id()
+out["build_id"] = os.environ.get("PROFILE_BUILD_ID") or _lib.source_build_id()   # the library the passes ran on
 path = os.path.join(root, "profiles", "raster_sq.json")
 json.dump(out, open(path, "w"), indent=1)
 print("wrote", path, {k: out[k] for k in ("kernel_us", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU") if k in out})
