@@ -872,24 +872,35 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
     }
     const int qq = tile * RTS + pl;
+    float ls = 0.0f, inv = 0.0f, k1 = 0.0f, gbu = 0.0f;
     if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
-      // what needs the pixel's 8 lanes: sum exp(score) and the labelled class' score; the per-pixel scalar arithmetic
-      // that follows from them runs ONCE per pixel on the block's first 4 waves after the loop (in here every lane
-      // of the pixel would repeat it: 8 x 35 instructions and six transcendentals per pixel)
       const float den = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
       const int t = lab[it];
       const float vt = (t & 2) ? ((t & 1) ? v[3] : v[2]) : ((t & 1) ? v[1] : v[0]);
       const float st = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);   // the labelled class' score in all 8 lanes (+ exact zeros)
-      if (c4 == 0) {
-        float *sl = frec + pl * 6;                             // (the record arena is free after the pair loop)
-        sl[0] = den; sl[1] = st; sl[2] = v[0]; sl[3] = wlab[it];
-        sl[4] = __int_as_float(t); sl[5] = __int_as_float((int)a[0]);
-      }
+      // (v_rcp_f32 / v_log_f32: 1 ulp and ~1e-7 absolute in log2 on p in [1e-7, 1) - far inside the loss head's 1e-4
+      // bar - where the IEEE division and logf() were a fifth of this phase's instructions)
+      inv = __builtin_amdgcn_rcpf(den);
+      const float sm = __expf(st) * inv;
+      const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
+      const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
+      const float om = 1.0f - p, lg = __logf(p), w = wlab[it];
+      const float pg = pow_gamma(om, lo.gamma);
+      ls = (unsigned)t < 32u ? pg * ((-lg) * w) : 0.0f;                          // :18, :41, :43-44
+      // d loss / d softmax_t (the clip passes gradient on [eps, 1 - eps] only) x softmax_t: with it
+      // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
+      k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
+      // what the background contributes to every channel's gradient where the clip's gate is open, per unit of k1
+      gbu = a[0] ? ((t == 0 ? 1.0f : 0.0f) - __expf(v[0]) * inv) : 0.0f;         // (lane c4 == 0: v[0] = background)
     }
     if (qq < npix && c4 < C) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
       const unsigned po = (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68); mesh base + 32-bit offset
       if (lo.vmax && c4 == 0) lo.vmax[(size_t)n * npix + po] = vmx;
+      if (LOSS && c4 == 0) {
+        lo.loss[(size_t)n * npix + po] = ls;
+        lo.stats[(size_t)n * npix + po] = make_float4(k1 * inv, k1 * gbu, k1, __int_as_float(lab[it]));
+      }
       float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
       if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
       } else if (c4 + 3 < C && (C & 3) == 0) {
@@ -901,32 +912,6 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       short4 o4;
       o4.x = a[0]; o4.y = a[1]; o4.z = a[2]; o4.w = a[3];
       *reinterpret_cast<short4 *>(arg + (size_t)n * npix * 32 + (po * 32u + (unsigned)c4)) = o4;
-    }
-  }
-  if (LOSS) {
-    __syncthreads();
-    const int qq = tile * RTS + tid;
-    if (tid < RTS && qq < npix) {                          // one lane per pixel: waves 4..15 are done
-      const float *sl = frec + tid * 6;
-      const float den = sl[0], st = sl[1], bg = sl[2], w = sl[3];
-      const int t = __float_as_int(sl[4]), gate = __float_as_int(sl[5]);
-      // (v_rcp_f32 / v_log_f32: 1 ulp and ~1e-7 absolute in log2 on p in [1e-7, 1) - far inside the loss head's 1e-4 bar)
-      const float inv = __builtin_amdgcn_rcpf(den);
-      const float sm = __expf(st) * inv;
-      const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
-      const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
-      const float om = 1.0f - p, lg = __logf(p);
-      const float pg = pow_gamma(om, lo.gamma);
-      const float ls = (unsigned)t < 32u ? pg * ((-lg) * w) : 0.0f;              // :18, :41, :43-44
-      // d loss / d softmax_t (the clip passes gradient on [eps, 1 - eps] only) x softmax_t: with it
-      // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
-      const float k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
-      // what the background contributes to every channel's gradient where the clip's gate is open, per unit of k1
-      const float gbu = gate ? ((t == 0 ? 1.0f : 0.0f) - __expf(bg) * inv) : 0.0f;
-      const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
-      const size_t po = (size_t)n * npix + (unsigned)((W - 1 - rr) * W + cc);   // rows flipped (:68)
-      lo.loss[po] = ls;
-      lo.stats[po] = make_float4(k1 * inv, k1 * gbu, k1, __int_as_float(t));
     }
   }
   SMPLR_TL_STAMP(6);

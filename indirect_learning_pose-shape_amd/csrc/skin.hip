@@ -96,91 +96,91 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
   }
 }
 
-// One block = SKB_NCH chunks of 256 vertices of ONE mesh, walked one after the other with the next chunk's operands
-// in flight: at B = 128 the one-chunk form ran as two rounds of 1 792 resident workgroups that all paid the operands'
-// two dependent hops (the vertex' record slot, then the slot's row-block sums: 2.7 us under the load of a whole round
-// asking at once) at the same moment and then queued on the matrix pipe together; three chunks per block are ONE round
-// (1 152 workgroups at 4.5 per CU), the hops of chunk k + 1 run under the arithmetic of chunk k, the mesh's joint
-// matrix is staged once, the dA tile stays in the MFMA accumulators across the chunks and is reduced and stored once:
-// 9 partials per mesh instead of 27 for pose_bwd to sum.  part layout per (mesh, block): 288 dA + 4 dcam floats.
+// (7 waves per SIMD: 3456 workgroups of 4 waves at B = 128 are then 1.93 rounds of the 1792 that fit, not 2.25 of 1536;
+// needs <= 72 registers: 65 with T built row by row)
+// One block = 256 vertices x SKB_MB meshes (the 24 skinning weights of a vertex are loaded once and
+// kept in registers / LDS for all of them).  part layout per (mesh, block): 288 dA + 4 dcam floats.
 #ifdef SMPLR_TL
 constexpr int TL_SKIN_WG = 3456;
 __device__ unsigned g_tl_skin[TL_SKIN_WG * (SKB_T / 64) * 32];
 #endif
 constexpr int SKB_PART = 292;
 constexpr int SKB_MB = 1;
-constexpr int SKB_NCH = 3;       // chunks of SKB_T vertices per block (V = 6890: 27 chunks = 9 blocks per mesh)
 
-// What one thread needs of its vertex of a chunk (everything that comes from global memory).
-struct SkbIn {
-  float4 ww, jj;                 // SPARSE: the <= 4 weights and joints
-  float p0, p1, p2;              // v_posed
-  float gv0, gv1, gv2;           // dverts
-  float gp0, gp1, gp2;           // dproj
-  int slot;                      // record slot of the vertex (segmentation gradient by vertex), -1: none
-};
-
-// LEAN: neither dverts nor dproj is given (the decoder's segmentation-only backward: the gradient arrives through the
-// record slots alone) - their six registers per chunk in flight are what keeps the pipelined form at five waves per SIMD.
-template <bool SPARSE, bool LEAN>
-__global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 5 : 2, 8))) void skin_bwd_kernel(
+template <bool SPARSE>
+__global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 7 : 4, 8))) void skin_bwd_kernel(
     const float *__restrict__ dverts, const float *__restrict__ dproj, const float *__restrict__ v_posed,
     const float *__restrict__ lbs, const float *__restrict__ top4, const float *__restrict__ A,
     const float *__restrict__ cam,
     int x_stride, int B, int V, int vs, int VP, float *__restrict__ dv_posed, float *__restrict__ part,
     const float *__restrict__ seg_part, const short *__restrict__ seg_vslot, int seg_nsplit) {
-  __shared__ float sG[2][SKB_T][4];    // g (3) per vertex, double-buffered by chunk parity
-  __shared__ float sP[2][SKB_T][4];    // [v_posed;1]
+  __shared__ float sG[SKB_T][4];    // g (3) per vertex
+  __shared__ float sP[SKB_T][4];    // [v_posed;1]
   __shared__ float sRed[SKB_T / 64][SKB_PART];
   __shared__ float4 sAj[72];        // this mesh's 24 x 12 joint matrix
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int v = blockIdx.x * SKB_T + tid;
+  const bool live = v < V;
+  const int vc = live ? v : V - 1;
+  const bool sampled = (vs <= 1) || (v % vs == 0);
+  const int vpi = (vs <= 1) ? v : v / vs;
+
   static_assert(SKB_MB == 1, "one mesh per block");
   const int n = blockIdx.y;                   // block-uniform
   SMPLR_TL_WAVE(g_tl_skin, SKB_T / 64, blockIdx.y * gridDim.x + blockIdx.x, TL_SKIN_WG)
+  // Every global operand of the block is requested here, before the first barrier: the weights,
+  // the mesh's joint matrix, the vertex and its incoming gradients (clamped, unconditional loads:
+  // a per-lane condition around a load costs a branch and a drained vmcnt each), so the block
+  // pays one round trip to memory instead of three.
+  float w[SPARSE ? 1 : 24];
+  if (!SPARSE) {
+    const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)vc * 24);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const float4 t = wp[q];
+      w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+    }
+  }
   const int li = lane & 15, lk = lane >> 4;
+  float w4[4] = {0.f, 0.f, 0.f, 0.f};
+  int jx[4] = {0, 0, 0, 0};
+  if (SPARSE) {
+    const float4 *tp = reinterpret_cast<const float4 *>(top4 + (size_t)vc * 8);
+    const float4 ww = tp[0], jj = tp[1];
+    w4[0] = ww.x; w4[1] = ww.y; w4[2] = ww.z; w4[3] = ww.w;
+    jx[0] = (int)jj.x; jx[1] = (int)jj.y; jx[2] = (int)jj.z; jx[3] = (int)jj.w;
+  }
+  const float4 aj = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid < 72 ? tid : 71];
+  const float *vp = v_posed + ((size_t)n * V + vc) * 3;
+  const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+  float gv0 = 0.f, gv1 = 0.f, gv2 = 0.f, gp0 = 0.f, gp1 = 0.f, gp2 = 0.f, ck0 = 0.f, ck1 = 0.f;
+  if (dverts) {                               // block-uniform
+    const float *d = dverts + ((size_t)n * V + vc) * 3;
+    gv0 = d[0]; gv1 = d[1]; gv2 = d[2];
+  }
   const bool has_proj = dproj || seg_vslot;   // block-uniform
-  const int nch = min(SKB_NCH, (V - (int)blockIdx.x * SKB_NCH * SKB_T + SKB_T - 1) / SKB_T);   // chunks of this block (>= 1)
-
-  // hop 1 of a chunk: everything addressed by the vertex (clamped, unconditional loads: a per-lane condition around
-  // a load costs a branch and a drained vmcnt each)
-  auto hop1 = [&](int ck, SkbIn &in) {
-    const int v = (blockIdx.x * SKB_NCH + ck) * SKB_T + tid;
-    const int vc = min(v, V - 1);
-    const int vpi = (vs <= 1) ? vc : vc / vs;
-    if (SPARSE) {
-      const float4 *tp = reinterpret_cast<const float4 *>(top4 + (size_t)vc * 8);
-      in.ww = tp[0];
-      in.jj = tp[1];
-    }
-    const float *vp = v_posed + ((size_t)n * V + vc) * 3;
-    in.p0 = vp[0]; in.p1 = vp[1]; in.p2 = vp[2];
-    in.gv0 = in.gv1 = in.gv2 = in.gp0 = in.gp1 = in.gp2 = 0.f;
-    in.slot = -1;
-    if (!LEAN && dverts) {                      // block-uniform
-      const float *d = dverts + ((size_t)n * V + vc) * 3;
-      in.gv0 = d[0]; in.gv1 = d[1]; in.gv2 = d[2];
-    }
-    if (!LEAN && dproj) {                       // block-uniform
-      const float *d = dproj + ((size_t)n * VP + min(vpi, VP - 1)) * 3;
-      in.gp0 = d[0]; in.gp1 = d[1]; in.gp2 = d[2];
-    }
-    if (seg_vslot) in.slot = seg_vslot[(size_t)n * VP + min(vpi, VP - 1)];   // block-uniform
-  };
-  // hop 2: d(seg)/d(proj) of the vertex = its record slot's sums over the segmentation backward's row blocks, added
-  // in block order (what seg_bwd_merge_kernel would have stored in dproj)
-  auto hop2 = [&](const SkbIn &in, float &sx, float &sy) {
-    sx = 0.0f;
-    sy = 0.0f;
-    if (!seg_vslot) return;                     // block-uniform
-    const int sl = max(in.slot, 0), win = sl / SB_SLOTS;
+  if (dproj) {                                // block-uniform
+    const float *d = dproj + ((size_t)n * VP + min(vpi, VP - 1)) * 3;
+    gp0 = d[0]; gp1 = d[1]; gp2 = d[2];
+  }
+  if (has_proj) {
+    const float *c = cam + (size_t)n * x_stride;
+    ck0 = c[0]; ck1 = c[1];
+  }
+  if (seg_vslot) {                            // block-uniform
+    // d(seg)/d(proj) of this vertex = its record slot's sums over the segmentation backward's row blocks,
+    // added in block order (what seg_bwd_merge_kernel would have stored in dproj); one extra hop: slot -> sums
+    const int slot = seg_vslot[(size_t)n * VP + min(vpi, VP - 1)];
+    const int sl = max(slot, 0), win = sl / SB_SLOTS;
     const float *sp = seg_part + ((size_t)n * seg_nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (sl - win * SB_SLOTS) * 2;
-    if (seg_nsplit <= 2) {                      // block-uniform: large batches (24 rows per row block, W <= 48)
+    float sx = 0.0f, sy = 0.0f;
+    if (seg_nsplit <= 2) {                    // block-uniform: large batches (24 rows per row block, W <= 48)
       const float2 t0 = *reinterpret_cast<const float2 *>(sp);
       const float2 t1 = *reinterpret_cast<const float2 *>(sp + (size_t)(seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
       sx = t0.x + (seg_nsplit > 1 ? t1.x : 0.0f);
       sy = t0.y + (seg_nsplit > 1 ? t1.y : 0.0f);
     } else {
-      constexpr int GC = 6;                     // row blocks requested together (W = 48 at 8 rows: all six)
+      constexpr int GC = 6;                   // row blocks requested together (W = 48 at 8 rows: all six)
       for (int s0 = 0; s0 < seg_nsplit; s0 += GC) {
         float2 t[GC];
 #pragma unroll
@@ -193,64 +193,27 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
         }
       }
     }
-  };
-
-  // ---- the block's first round trip: chunk 0's vertex operands, the mesh's joint matrix and camera
-  SkbIn cur;
-  hop1(0, cur);
-  const float4 aj = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid < 72 ? tid : 71];
-  float ck0 = 0.f, ck1 = 0.f;
-  if (has_proj) {
-    const float *c = cam + (size_t)n * x_stride;
-    ck0 = c[0]; ck1 = c[1];
+    if (slot >= 0) { gp0 += sx; gp1 += sy; }
   }
-  float sx, sy;
-  hop2(cur, sx, sy);                            // (second hop of chunk 0: exposed, once per block)
   if (tid < 72) sAj[tid] = aj;
   SMPLR_TL_STAMP(1);
   __syncthreads();
   SMPLR_TL_STAMP(2);
 
   const int cr = li >> 2, cc = li & 3;   // dT component j = li = r*4+c  (valid for li < 12)
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
 
-  for (int ck = 0; ck < nch; ++ck) {
-    const int v = (blockIdx.x * SKB_NCH + ck) * SKB_T + tid;
-    const bool live = v < V;
-    const bool sampled = (vs <= 1) || (v % vs == 0);
-    // the next chunk's first hop, in flight during this chunk's arithmetic
-    // (dense rows read all 72 rows of the joint matrix with compile-time addresses: without this the compiler hoists
-    // those 288 values out of the chunk loop - into registers it does not have)
-    if (!SPARSE) asm volatile("" ::: "memory");
-    SkbIn nxt = cur;
-    const bool more = ck + 1 < nch;             // block-uniform
-    if (SPARSE && more) hop1(ck + 1, nxt);      // (dense rows: 24 weights per vertex leave no registers for it)
-
-    float w[SPARSE ? 1 : 24];
-    if (!SPARSE) {                              // (dense rows: the 24 weights, requested here - no sparse form to carry)
-      const float4 *wp = reinterpret_cast<const float4 *>(lbs + (size_t)min(v, V - 1) * 24);
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const float4 t = wp[q];
-        w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
-      }
-    }
-    const float w4[4] = {cur.ww.x, cur.ww.y, cur.ww.z, cur.ww.w};
-    const int jx[4] = {(int)cur.jj.x, (int)cur.jj.y, (int)cur.jj.z, (int)cur.jj.w};
-    float gp0 = cur.gp0, gp1 = cur.gp1;
-    const float gp2 = cur.gp2, p0 = cur.p0, p1 = cur.p1, p2 = cur.p2;
-    if (seg_vslot && cur.slot >= 0) { gp0 += sx; gp1 += sy; }
-
-    // T = sum_j w_j A_j with the mesh's joint matrix staged in LDS (broadcast ds_read_b128), one ROW of T at a time
-    // (4 live values instead of 12): row r gives dv_posed its g_r terms, rows 0 and 1 the projected X and Y
+  {
+    // T = sum_j w_j A_j with the mesh's joint matrix staged in LDS (broadcast ds_read_b128) and
+    // w_j taken from LDS as well: as scalar operands the 288 matrix entries need more SGPRs than
+    // exist (the compiler then spills through v_readlane or falls back to 288 vector loads).
+    // ... one ROW of T at a time (4 live values instead of 12: the kernel's register peak was here, and 72 registers
+    // are what a seventh wave per SIMD needs): row r gives dv_posed its g_r terms, rows 0 and 1 the projected X and Y
     const bool proj_on = live && has_proj && sampled;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (live) { g0 = cur.gv0; g1 = cur.gv1; g2 = cur.gv2; }
+    float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
+    if (live) { g0 = gv0; g1 = gv1; g2 = gv2; }
     // (explicit fmas: the sparse and the dense instantiation must round alike, whatever the compiler would contract)
-    if (proj_on) { g0 = fmaf(ck0, gp0, g0); g1 = fmaf(ck1, gp1, g1); g2 += gp2; du0 += gp0; dv0 += gp1; }
+    if (proj_on) { g0 = fmaf(ck0, gp0, g0); g1 = fmaf(ck1, gp1, g1); g2 += gp2; du0 = gp0; dv0 = gp1; }
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -266,7 +229,7 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
       dp0 = fmaf(t0, gr, dp0); dp1 = fmaf(t1, gr, dp1); dp2 = fmaf(t2, gr, dp2);
       if (r < 2 && proj_on) {
         const float XY = fmaf(t2, p2, fmaf(t1, p1, fmaf(t0, p0, t3)));
-        if (r == 0) dku += XY * gp0; else dkv += XY * gp1;
+        if (r == 0) dku = XY * gp0; else dkv = XY * gp1;
       }
     }
     if (live) {
@@ -276,37 +239,37 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
     // A operand of the dA product, straight from the (L2-resident) weight table in MFMA layout:
     // lane (li, lk) of step s holds w[vertex 64 wave + 4 s + lk][joint li] and [joint 16 + li]
     // (4 rows x 64-B segments per load); 32 loads per wave, requested once T is done (their latency
-    // overlaps the barrier; asked for at the top they cost 32 live registers).  Buffer loads: a descriptor of the
-    // weight table (wave-uniform) + ONE 32-bit byte offset per lane + an immediate per step, rows past the end of
-    // the table read as 0 (the hardware's range check; their vertices carry g = 0 anyway).
+    // overlaps the barrier; asked for at the top they cost 32 live registers = one wave per SIMD).
     SMPLR_TL_STAMP(3);
     float wa0[8], wa1[8];        // a ring of 8 steps: steps 8..15 are requested as the first eight are consumed
-    const int vb = (blockIdx.x * SKB_NCH + ck) * SKB_T + wave * 64 + lk;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
+    const int vb = blockIdx.x * SKB_T + wave * 64 + lk;
     const int o0 = (vb * 24 + li) * 4, o1 = (vb * 24 + 16 + (li & 7)) * 4;
-#pragma unroll
-    for (int sI = 0; sI < 8; ++sI) {
-      wa0[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o0 + sI * 384, 0, 0));
-      wa1[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o1 + sI * 384, 0, 0));
+    {
+      // buffer loads: a 128-bit descriptor of the weight table (wave-uniform) + ONE 32-bit byte offset per lane
+      // + an immediate per step, rows past the end of the table read as 0 (the hardware's range check; their
+      // vertices carry g = 0 anyway) - instead of a clamp and a 64-bit multiply-add per request (a fifth of
+      // the kernel's vector instructions)
+  #pragma unroll
+      for (int sI = 0; sI < 8; ++sI) {
+        wa0[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o0 + sI * 384, 0, 0));
+        wa1[sI] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o1 + sI * 384, 0, 0));
+      }
     }
-    float(*bG)[4] = sG[ck & 1];
-    float(*bP)[4] = sP[ck & 1];
-    bG[tid][0] = g0; bG[tid][1] = g1; bG[tid][2] = g2; bG[tid][3] = 0.f;
-    bP[tid][0] = p0; bP[tid][1] = p1; bP[tid][2] = p2; bP[tid][3] = 1.0f;
-    // (one barrier per chunk: the buffers alternate, and a wave cannot be two chunks ahead of another - it would have
-    // had to pass the barrier in between)
+    sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = g2; sG[tid][3] = 0.f;
+    sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
     __syncthreads();
     SMPLR_TL_STAMP(4);
-    // the next chunk's second hop (its record slot has arrived under the arithmetic above), in flight during the MFMAs
-    float nsx = 0.f, nsy = 0.f;
-    if (SPARSE && more) hop2(nxt, nsx, nsy);
 
     // dA tile on the matrix cores: D[joint][comp] += sum_k w[vk][joint] * g[vk][comp>>2]*ph[vk][comp&3]
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int t = wave * 64 + s * 4 + lk;     // tail vertices carry g = 0 and finite (clamped) weights
       const float a0 = wa0[s & 7];
       const float a1 = (li < 8) ? wa1[s & 7] : 0.0f;
-      const float b = (li < 12) ? bG[t][cr] * bP[t][cc] : 0.0f;
+      const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
       if (s < 8) {
@@ -315,36 +278,29 @@ __global__ __launch_bounds__(SKB_T) __attribute__((amdgpu_waves_per_eu(SPARSE ? 
       }
     }
     SMPLR_TL_STAMP(5);
-    if (!SPARSE && more) {                      // dense rows: the next chunk's two hops, one after the other
-      hop1(ck + 1, nxt);
-      hop2(nxt, nsx, nsy);
-    }
-    cur = nxt;
-    sx = nsx;
-    sy = nsy;
-  }
-  // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
-  if (li < 12) {
+    // C/D layout 16x16: col = lane&15 (component), row = (lane>>4)*4 + reg (joint in tile)
+    if (li < 12) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j0 = lk * 4 + r;
-      sRed[wave][j0 * 12 + li] = acc0[r];
-      if (j0 < 8) sRed[wave][(16 + j0) * 12 + li] = acc1[r];
+      for (int r = 0; r < 4; ++r) {
+        const int j0 = lk * 4 + r;
+        sRed[wave][j0 * 12 + li] = acc0[r];
+        if (j0 < 8) sRed[wave][(16 + j0) * 12 + li] = acc1[r];
+      }
     }
-  }
-  const float r0 = wave_sum(dku), r1 = wave_sum(dkv), r2 = wave_sum(du0), r3 = wave_sum(dv0);
-  if (lane == 0) {
-    sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
-  }
-  __syncthreads();
-  SMPLR_TL_STAMP(6);
-  for (int e = tid; e < SKB_PART; e += SKB_T) {
-    float acc = 0.f;
+    const float r0 = wave_sum(dku), r1 = wave_sum(dkv), r2 = wave_sum(du0), r3 = wave_sum(dv0);
+    if (lane == 0) {
+      sRed[wave][288] = r0; sRed[wave][289] = r1; sRed[wave][290] = r2; sRed[wave][291] = r3;
+    }
+    __syncthreads();
+    SMPLR_TL_STAMP(6);
+    for (int e = tid; e < SKB_PART; e += SKB_T) {
+      float acc = 0.f;
 #pragma unroll
-    for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
-    part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
+      for (int wv = 0; wv < SKB_T / 64; ++wv) acc += sRed[wv][e];
+      part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
+    }
+    SMPLR_TL_STAMP(7);
   }
-  SMPLR_TL_STAMP(7);
 }
 
 __global__ __launch_bounds__(320) void skin_bwd_reduce_kernel(const float *__restrict__ part, int nblk,
@@ -402,22 +358,21 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restric
   if (tid < 4) dcam[(size_t)n * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-int skin_bwd_nblk(int V) { return (V + SKB_T * SKB_NCH - 1) / (SKB_T * SKB_NCH); }
+int skin_bwd_nblk(int V) { return (V + SKB_T - 1) / SKB_T; }
 
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
                              int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st) {
   const int VP = (V + vs - 1) / vs;
   const dim3 grid(skin_bwd_nblk(V), (B + SKB_MB - 1) / SKB_MB);
-#define SMPLR_SKB_LAUNCH(SPARSE_, LEAN_)                                                                                \
-  hipLaunchKernelGGL((skin_bwd_kernel<SPARSE_, LEAN_>), grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights,  \
-                     lbs_top4, A, cam, x_stride, B, V, vs, VP, dv_posed, part, sg.part,                                 \
-                     reinterpret_cast<const short *>(sg.vslot), sg.nsplit)
-  const bool lean = !dverts && !dproj;
-  if (lbs_top4 && lean) SMPLR_SKB_LAUNCH(true, true);
-  else if (lbs_top4) SMPLR_SKB_LAUNCH(true, false);
-  else SMPLR_SKB_LAUNCH(false, false);
-#undef SMPLR_SKB_LAUNCH
+  if (lbs_top4)
+    hipLaunchKernelGGL(skin_bwd_kernel<true>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
+                       A, cam, x_stride, B, V, vs, VP, dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot),
+                       sg.nsplit);
+  else
+    hipLaunchKernelGGL(skin_bwd_kernel<false>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
+                       A, cam, x_stride, B, V, vs, VP, dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot),
+                       sg.nsplit);
   SMPLR_LAUNCH_CHECK("skin_bwd_kernel");
   return 0;
 }
@@ -452,7 +407,7 @@ int smplr_skin_fwd(const float *v_posed, const float *lbs_weights, const float *
 size_t smplr_skin_bwd_workspace(int B, int V) {
   using namespace smplr;
   if (B <= 0 || V <= 0) return 0;
-  return (size_t)B * skin_bwd_nblk(V) * SKB_PART * sizeof(float);
+  return (size_t)B * ((V + SKB_T - 1) / SKB_T) * SKB_PART * sizeof(float);
 }
 
 int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed,

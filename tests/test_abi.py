@@ -48,7 +48,7 @@ def test_ctypes_table_matches_header():
     assert rc == -1 and b"smplr_skin_vis_seg_fwd" in lib.smplr_last_error()
     assert lib.smplr_skin_vis_seg_fwd(None, None, None, None, 86, 0, 6890, 48, 64, 1, None, None, 31, 6879, None, None,
                                       None, None, None, None, None, None, None) == 0
-    assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 9 * 292 * 4      # 9 blocks of 3 x 256 vertices per mesh
+    assert lib.smplr_skin_bwd_workspace(128, 6890) == 128 * 27 * 292 * 4
     # the skinning form of the binning kernel needs the mesh's staged (u, v) in LDS beside the 64 x 64 z-buffer, the
     # pixel counters and the slot map: it fits the reference's raster sizes, not the largest ones the ABI accepts
     assert lib.smplr_skin_vis_seg_fits(6890, 48, 64) == 1 and lib.smplr_skin_vis_seg_fits(6890, 96, 64) == 1
