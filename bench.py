@@ -597,10 +597,12 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
+        import datetime
+        to = datetime.timedelta(minutes=5)          # (a rank that dies mid-collective must not hang the others for 10 min)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=to)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=to)
 
     B, W = args.batch, args.wh
     model = synthetic_smpl_model(1234)
@@ -714,10 +716,9 @@ def main():
     if not args.no_train_leg:
         try:
             tleg = train_leg(args, rank, world, dev, dist, backend, model, W)
-        except Exception as e:
-            if world > 1:
-                raise                       # ranks would desynchronise: fail the run loudly
-            tleg = {"error": str(e)}
+        except Exception as e:              # the decoder line must still come out: the leg's failure is reported in it
+            tleg = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("bench: train leg failed on rank %d: %s\n" % (rank, tleg["error"]))
 
     line = None
     if rank == 0:
@@ -991,8 +992,11 @@ def main():
                 line["parity"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:              # (only reachable after a failed leg: the line is already out)
+            sys.stderr.write("bench: process group shutdown: %s\n" % e)
 
 
 if __name__ == "__main__":
