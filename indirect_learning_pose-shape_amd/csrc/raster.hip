@@ -31,7 +31,6 @@
 // runs of pixels that share an arg-min are summed in registers and reach the block's LDS slot
 // accumulators (ds_add_f32) only at run boundaries; per-block slot sums are merged in a fixed
 // order and scattered to the vertices with plain stores (no global atomics, no memset).
-#include <stdlib.h>
 #include "common.h"
 
 namespace smplr {
@@ -423,7 +422,6 @@ constexpr int ALD = 34;          // arg tile row stride (shorts per pixel: 17 dw
 #endif
 constexpr int RTS = SMPLR_RASTER_BT / NG;   // pixels per segmentation raster block
 constexpr int WPT = RTS / 64;    // 64-pixel sub-tiles per block
-static_assert(SMPLR_RASTER_BT != 1024 || (RTS == 256 && NG == 4), "the half-block form assumes 256-pixel tiles x 4 ranges");
 constexpr int PART_COST = 16;    // fixed cost of a part in the balance, in records (exp, sqrt, winner re-scan; 4: +0.4 us)
 constexpr int NREC = 1024;      // records of a mesh's global list that fit the block's LDS copy (per field)
 // LDS arena of a block, in floats: u[NREC] | v[NREC] | m^2[NREC] | tables of (v - row)^2, one row of the table per
@@ -632,7 +630,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
                                                              const int *__restrict__ goff,
                                                              const int *__restrict__ lstart,
                                                              const uint2 *__restrict__ lrec, int P, int K,
-                                                             int S, int W, int B, int ntiles, int nfull,
+                                                             int S, int W, int B, int ntiles,
                                                              float *__restrict__ seg, short *__restrict__ arg,
                                                              unsigned wmagic, LossOut lo) {
   __shared__ float sS[RTS * SLD];
@@ -640,29 +638,17 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   __shared__ f32x4 sRec[ARENA / 4];      // records, field-major: u[NREC] | v[NREC] | m^2[NREC]; row tables
   // XCD-aware map: mesh m lives on XCD m % 8 (blocks b and b+8 share an L2), its tiles are
   // consecutive there, so a mesh's record list is fetched into one L2 and re-read from it.
-  // The first nfull blocks take whole tiles of RTS pixels (ntiles per mesh).  Blocks beyond them are HALF blocks:
-  // the launcher cuts a mesh's last tile into two when the whole tiles fill an exact number of rounds of the chip's
-  // 512 block slots and the rest would run one block per CU on half the CUs (B = 128, W = 48: 1 024 whole blocks =
-  // two rounds, then 256 half blocks, one per CU, instead of 128 whole ones on 128 CUs): 8 waves, 128 pixels.
   const int bid = blockIdx.x;
-  const bool half = bid >= nfull;                        // block-uniform
-  const int b2 = half ? bid - nfull : bid;
-  const int xcd = b2 & 7, idx = b2 >> 3;
-  const int tpm = half ? 2 : ntiles;                     // blocks of this kind per mesh
-  const int n = (idx / tpm) * 8 + xcd, ti = idx % tpm;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int n = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
   if (n >= B) return;                                    // block-uniform
-  const int npx = half ? RTS / 2 : RTS;                  // pixels of this block
-  const int pbase = half ? ntiles * RTS + ti * (RTS / 2) : ti * RTS;
-  const int nthr = npx * NG;
   const int tid = threadIdx.x, lane = tid & 63;
-  if (tid >= nthr) return;                               // a half block's waves 8..15 (before any barrier)
-  SMPLR_TL_WAVE(g_tl_raster, 16, bid, TL_RASTER_WG)
+  SMPLR_TL_WAVE(g_tl_raster, 16, n * ntiles + tile, TL_RASTER_WG)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keep it scalar
-  const int wsh = half ? 1 : 2;                          // pixel sub-tiles per block = 1 << wsh (RTS = 256)
-  const int g = wave >> wsh, pw = wave & ((1 << wsh) - 1);   // part range, pixel sub-tile
+  const int g = wave / WPT, pw = wave % WPT;             // part range, pixel sub-tile
   const int pt = pw * 64 + lane;                         // pixel within the tile
   const int npix = W * W;
-  const int q = pbase + pt;
+  const int q = tile * RTS + pt;
   const int qc = q < npix ? q : npix - 1;
   // q / W for q < W^2 <= 25600 as a multiply and a shift (wmagic = ceil(2^24 / W), exact there): the
   // compiler's sequence for a division by a run-time W is ~20 instructions, three times per lane
@@ -681,7 +667,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   int lab[NIT];                                          // LOSS: the label of each of this lane's merge pixels
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int qq = pbase + ((it * nthr + tid) >> 3);
+    const int qq = tile * RTS + ((it * (RTS * NG) + tid) >> 3);
     const int *lp = lstart + (size_t)n * (npix + 1) + (qq < npix ? qq : npix - 1);
     l0a[it] = lp[0];
     l1a[it] = qq < npix ? lp[1] : 0;                     // pixels past the image merge nothing
@@ -702,7 +688,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   // (in-order, counted waits); longer lists use the scalar-load path below.  Both evaluate the
   // same fp32 expressions.
   float *const frec = reinterpret_cast<float *>(sRec);
-  for (int i = tid; i < NREC; i += nthr) {
+#pragma unroll
+  for (int i = tid; i < NREC; i += RTS * NG) {
     // thread i copies record i before the list length is even known (slots beyond it hold stale
     // bytes nobody reads), so the copy shares the first round trip to memory
     const float4 t = Gn[min(i, S - 1)];
@@ -713,8 +700,8 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   const bool in_lds = lbase <= NREC;                     // block-uniform
   // (v - row)^2 of every record for the image rows this block touches (6 at W = 48), so that a pair costs
   // a subtract and an fma instead of two subtracts, a multiply and an fma; used when the tables fit
-  const int row0 = (int)(((unsigned)min(pbase, npix - 1) * wmagic) >> 24);
-  const int nrows = (int)(((unsigned)min(pbase + npx - 1, npix - 1) * wmagic) >> 24) - row0 + 1;
+  const int row0 = (int)(((unsigned)min(tile * RTS, npix - 1) * wmagic) >> 24);
+  const int nrows = (int)(((unsigned)min(tile * RTS + RTS - 1, npix - 1) * wmagic) >> 24) - row0 + 1;
   // table row stride: consecutive rows (the most a 16-lane read group spans) must not share banks
   const int lb4 = (lbase + 3) & ~3;
   const int RS = ((lb4 & 63) >= 4 && (lb4 & 63) <= 60) ? lb4 : lb4 + 4;
@@ -732,7 +719,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
     const int n4 = (lbase + 3) >> 2, k4 = tid & 255;
     if (k4 < n4) {
       const f32x4 v = sRec[NREC / 4 + k4];
-      for (int j = tid >> 8; j < nrows; j += nthr >> 8) {
+      for (int j = tid >> 8; j < nrows; j += (RTS * NG) >> 8) {
         const float frj = (float)(row0 + j);
         const f32x4 dv = v - frj;
         *reinterpret_cast<f32x4 *>(frec + toff + j * RS + 4 * k4) = dv * dv;
@@ -837,7 +824,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   // it further.  LDS operations of one wave execute in order, so no barrier separates merge and write-out.
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int e = it * nthr + tid;
+    const int e = it * (RTS * NG) + tid;
     const int pl = e >> 3, c4 = (e & 7) * 4;
     {
       int *rowS = reinterpret_cast<int *>(&sS[pl * SLD + 1]);
@@ -884,7 +871,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       v[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
       a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
     }
-    const int qq = pbase + pl;
+    const int qq = tile * RTS + pl;
     float ls = 0.0f, inv = 0.0f, k1 = 0.0f, gbu = 0.0f;
     if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
       const float den = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
@@ -2094,21 +2081,13 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
   const char *base = reinterpret_cast<const char *>(workspace);
-  // whole tiles per mesh, and whether the last one runs as two half blocks (see raster_fwd_kernel): when the other
-  // tiles' blocks fill whole rounds of the chip's 512 block slots (2 per CU) and the last tiles alone would not fill
-  // a quarter of a round (at most one block on every other CU).  SMPLR_RASTER_SPLIT=0/1 forces it (A/B runs, tests).
-  int ntiles = (W * W + RTS - 1) / RTS;
-  const int bp = 8 * ((B + 7) / 8);
-  bool split = SMPLR_RASTER_BT == 1024 && ntiles >= 2 && (bp * (ntiles - 1)) % 512 == 0 && bp <= 128;
-  if (const char *e = getenv("SMPLR_RASTER_SPLIT")) split = SMPLR_RASTER_BT == 1024 && ntiles >= 2 && e[0] == '1';
-  if (split) --ntiles;
-  const int nfull = bp * ntiles;
-  const int grid = nfull + (split ? bp * 2 : 0);
+  const int ntiles = (W * W + RTS - 1) / RTS;
+  const int grid = 8 * ((B + 7) / 8) * ntiles;
 #define SMPLR_RASTER_LAUNCH(LOSS_)                                                                             \
   hipLaunchKernelGGL(raster_fwd_kernel<LOSS_>, dim3(grid), dim3(RTS * NG), 0, as_stream(stream),               \
                      reinterpret_cast<const float4 *>(rec), reinterpret_cast<const int *>(base + ws.goff_off), \
                      reinterpret_cast<const int *>(base + ws.lstart_off),                                      \
-                     reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, nfull, seg,   \
+                     reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, seg,          \
                      reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W), lo)
   if (with_loss) SMPLR_RASTER_LAUNCH(true);
   else SMPLR_RASTER_LAUNCH(false);

@@ -988,32 +988,3 @@ def test_fused_pose_blend_equals_separate_calls(smpl_model, B):
     torch.cuda.synchronize()
     for a, b, name in ((Rs, Rs2, "Rs"), (J, J2, "J"), (A, A2, "A"), (Jt, Jt2, "J_transformed"), (vp, vp2, "v_posed")):
         assert torch.equal(a, b), name
-
-
-@pytest.mark.parametrize("B,W", [(128, 48), (3, 48), (2, 50), (5, 64)])
-def test_raster_half_blocks_change_nothing(layer, B, W, monkeypatch):
-    """The rasteriser may run a mesh's last tile as two half blocks (a launch-geometry choice: B = 128, W = 48 then
-    fills the chip's block slots in whole rounds): scores and arg-min slots are bit for bit those of whole tiles,
-    also where the last tile is partial (W = 50) and with the loss epilogue."""
-    from ilps_amd import ops
-    from ilps_amd.keras_smpl.compute_mask import compute_mask
-    from ilps_amd.keras_smpl.projection import orthographic_project
-    x = t(make_x(B, W, seed=B * W))
-    with torch.no_grad():
-        proj = orthographic_project([layer(x), x], None).contiguous()
-        mask = compute_mask(proj)
-    pt = ops.get_part_table(1, proj.device, 6890)
-    ws, rec = ops._seg_bin(proj, mask, W, pt)
-    lab = torch.randint(0, 32, (B, W, W), device=dev(), dtype=torch.int32)
-    outs = []
-    for split in ("0", "1"):
-        monkeypatch.setenv("SMPLR_RASTER_SPLIT", split)
-        seg, arg = ops._seg_raster(ws, rec, B, W, pt)
-        loss, stats, arg2 = ops._seg_raster_ex(ws, rec, B, W, pt, lab, None, 2.0)
-        torch.cuda.synchronize()
-        outs.append((seg, arg, loss, stats, arg2))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-    monkeypatch.delenv("SMPLR_RASTER_SPLIT")
-    seg, arg = ops._seg_raster(ws, rec, B, W, pt)                 # the launcher's own choice
-    assert torch.equal(seg, outs[0][0]) and torch.equal(arg, outs[0][1])
