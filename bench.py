@@ -157,8 +157,8 @@ def raster_roofline(x, consts, pt, W, stages):
       frac     = achieved / 157.3: a true fraction (< 1)
       algorithmic_* = the brute-force count SURVEY 8(d) prices (W*W x 6879 pairs per mesh) over the same time: how
                  much arithmetic the reach split makes unnecessary - a speed-up factor, not a utilisation
-    Launch time: HIP events on the launch stream around graph-replayed back-to-back launches of smplr_seg_raster
-    (includes the ~1-2 us dispatch gap; the rocprofv3 kernel average is in profiles/).  valu_* come from the
+    Launch time: HIP events on the launch stream around the kernel's launch (smplr_seg_raster) inside an eager step of
+    the step's own kernels (includes the event records' dispatch gap; the rocprofv3 kernel average is in profiles/).  valu_* come from the
     committed SQ counter pass of the same kernel (profiles/raster_sq.json), traffic from the FETCH/WRITE passes."""
     B, V = x.shape[0], consts.V
     st = torch.cuda.current_stream()
@@ -168,7 +168,32 @@ def raster_roofline(x, consts, pt, W, stages):
     ws, rec = ops._seg_bin(proj, mask, W, pt, grid_wh=64)
     seg, arg = ops._seg_raster(ws, rec, B, W, pt)
     t_bin = graph_time_ms(lambda: ops._seg_bin(proj, mask, W, pt, grid_wh=64, rec=rec, ws=ws), 20, st) * 1e-3
-    t_ras = graph_time_ms(lambda: ops._seg_raster(ws, rec, B, W, pt, out=(seg, arg)), 20, st) * 1e-3
+    t_iso = graph_time_ms(lambda: ops._seg_raster(ws, rec, B, W, pt, out=(seg, arg)), 20, st) * 1e-3
+    # the kernel's launch time INSIDE the step it belongs to: HIP events on the launch stream right around the raster
+    # launch of an eager step made of the same kernels (pose + blend, skinning, binning, [raster], seg_bwd, smpl_bwd).
+    # Twenty copies of this one kernel replayed back to back (t_iso) run 10-15 % slower than the same kernel in the
+    # step - an uninterrupted vector-issue-bound stream holds a lower clock - and it is the step's kernel that the
+    # rocprofv3 trace of `bench.py --mode eager` averages (profiles/)
+    dseg_r = torch.randn_like(seg)
+    vslot_r = torch.empty(B, pt.VP, dtype=torch.int16, device=x.device)
+    nrep = 60
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nrep)]
+    for i in range(nrep + 10):
+        Rs_, J_, A_, Jt_, vp_ = ops._pose_blend_fwd(x, 4, consts) if consts.blend3_fwd is not None else (None,) * 5
+        if vp_ is None:
+            coef_, Rs_, J_, A_, Jt_ = ops._pose_fwd(x, 4, consts)
+            vp_ = ops._blend_fwd(coef_, consts, B)
+        pj_ = ops._skin_fwd(vp_, A_, consts, cam=x)[1]
+        ops._seg_bin(pj_, mask, W, pt, grid_wh=64, rec=rec, ws=ws, vslot=vslot_r)
+        if i >= 10:
+            evs[i - 10][0].record(st)
+        ops._seg_raster(ws, rec, B, W, pt, out=(seg, arg))
+        if i >= 10:
+            evs[i - 10][1].record(st)
+        part_, ns_ = ops._seg_bwd(dseg_r, arg, rec, pt.VP, W, pt, merge=False)
+        ops._smpl_bwd(x, 4, consts, Rs_, J_, A_, vp_, None, None, None, seg_grad=(part_, vslot_r, ns_))
+    torch.cuda.synchronize()
+    t_ras = float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
     # far-reaching records per mesh, counted on the device: part-table vertices whose mask is <= 208 (here: == 1)
     far = (mask[:, pt.part_pos.long()] <= 208.0).sum(dim=1).double()
     n_far = float(far.mean().item())
@@ -178,7 +203,10 @@ def raster_roofline(x, consts, pt, W, stages):
     brute = float(W * W) * pt.K * B                                  # every pixel x every part vertex
     out = {"kernel": "raster_fwd_kernel (smplr_seg_raster)", "bound": "mfma", "pipe": "fp32 VALU (vector peak = fp32 matrix peak)",
            "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
-           "traffic": None, "launch_us": round(t_ras * 1e6, 2), "bin_launch_us": round(t_bin * 1e6, 2),
+           "traffic": None, "launch_us": round(t_ras * 1e6, 2), "launch_us_isolated_replay": round(t_iso * 1e6, 2),
+           "launch_us_how": "median of 60 HIP-event pairs on the launch stream around the kernel's launch inside an eager "
+                            "step of the same seven kernels; isolated_replay = 20 back-to-back copies from one HIP graph",
+           "bin_launch_us": round(t_bin * 1e6, 2),
            "far_records_per_mesh": round(n_far, 1), "executed_pairs_per_launch": int(pairs), "flop_per_pair": 7,
            "algorithmic_pairs_per_launch": int(brute), "algorithmic_speedup": round(brute / pairs, 2),
            "algorithmic_equiv_tflops": round((brute * 7.0 + W * W * pt.P * 2.0 * B) / t_ras / 1e12, 2),

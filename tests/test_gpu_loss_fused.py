@@ -180,17 +180,19 @@ def test_fused_loss_argument_errors(layer):
     assert lib.smplr_seg_loss_bwd(None, None, None, None, 0, 6890, 48, 31, 6879, None, None, 0, None) == 0
 
 
-@pytest.mark.parametrize("B,W,with_silh", [(3, 48, False), (128, 48, False), (5, 48, True), (2, 64, False), (2, 128, False)])
-def test_decoder_with_fused_loss_equals_unfused(smpl_model, B, W, with_silh):
+@pytest.mark.parametrize("B,W,with_silh,vs", [(3, 48, False, None), (128, 48, False, None), (5, 48, True, None),
+                                              (2, 64, False, None), (2, 128, False, None), (3, 48, False, 5)])
+def test_decoder_with_fused_loss_equals_unfused(smpl_model, B, W, with_silh, vs):
     """SMPLDecoder(loss=softmax_focal_loss(...)): forward(x, labels) returns the per-pixel loss without ever writing
-    the scores; loss and dx agree with the unfused decoder + loss head.  W = 128 takes the two-call path (the
-    skinning form of the binning kernel does not fit there), B = 128 is BASELINE configs[2]'s batch."""
+    the scores; loss and dx agree with the unfused decoder + loss head.  W = 128 and vertex_sampling = 5 take the
+    two-call path (the skinning form of the binning kernel does not apply there), B = 128 is BASELINE configs[2]'s batch."""
     from ilps_amd.decoder import SMPLDecoder
     from ilps_amd.focal_loss import softmax_focal_loss
     x = make_x(B, W, seed=B + W)
     lf = softmax_focal_loss(2.0, True)
-    plain = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh)
-    fused = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, loss=lf, outputs=(), keep_seg=True)
+    plain = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, vertex_sampling=vs)
+    fused = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, vertex_sampling=vs, loss=lf, outputs=(),
+                        keep_seg=True)
     rng = np.random.default_rng(B)
     xa = t(x).requires_grad_(True)
     oa = plain(xa)
