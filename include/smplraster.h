@@ -240,6 +240,12 @@ int smplr_seg_bin(const float *proj, float *mask, int B, int VP, int W, int grid
                   int16_t *vslot, void *stream);
 int smplr_seg_raster(int B, int W, int P, int K, const void *workspace, const float *rec, float *seg,
                      int16_t *arg, void *stream);
+/* Measurement aid (bench.py's roofline): smplr_seg_raster with start / stop events ON the launch (hipExtLaunchKernel);
+ * the call WAITS for the kernel and returns its own duration in *kernel_ms (host pointer) - begin to end on the device,
+ * the quantity rocprofv3's kernel trace reports, without the dispatch gap that events recorded around a launch
+ * include.  Not capturable, synchronises: never on the product path.                                            */
+int smplr_seg_raster_timed(int B, int W, int P, int K, const void *workspace, const float *rec, float *seg,
+                           int16_t *arg, float *kernel_ms, void *stream);
 
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:

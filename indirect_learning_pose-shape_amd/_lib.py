@@ -58,6 +58,7 @@ SIGNATURES = {
     "smplr_skin_vis_seg_fwd": (c_int, [P, P, P, P, I, I, I, I, I, I, P, P, I, I, P, P, P, P, P, P, P, P, P]),
     "smplr_seg_bin": (c_int, [P, P, I, I, I, I, I, P, P, I, I, P, P, P, P]),
     "smplr_seg_raster": (c_int, [I, I, I, I, P, P, P, P, P]),
+    "smplr_seg_raster_timed": (c_int, [I, I, I, I, P, P, P, P, P, P]),
     "smplr_seg_bwd_nsplit": (c_int, [I, I]),
     "smplr_seg_bwd_workspace": (c_size_t, [I, I]),
     "smplr_seg_bwd": (c_int, [P, P, P, I, I, I, I, I, P, P, I, P]),

@@ -31,6 +31,7 @@
 // runs of pixels that share an arg-min are summed in registers and reach the block's LDS slot
 // accumulators (ds_add_f32) only at run boundaries; per-block slot sums are merged in a fixed
 // order and scattered to the vertices with plain stores (no global atomics, no memset).
+#include <hip/hip_ext.h>
 #include "common.h"
 
 namespace smplr {
@@ -2068,8 +2069,11 @@ static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fus
 }
 
 // stage 2: the pair loop + merge + write-out over a binned workspace
+// kernel_ms != NULL: the launch carries start / stop events (hipExtLaunchKernel) and the call WAITS for the kernel and
+// returns its own duration - begin to end on the device, what rocprofv3's kernel trace reports, without the dispatch
+// gap an event pair around a launch includes.  A measurement aid for bench.py's roofline only.
 static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const void *workspace, const float *rec,
-                           float *seg, int16_t *arg, void *stream, LossOut lo = LossOut{}) {
+                           float *seg, int16_t *arg, void *stream, LossOut lo = LossOut{}, float *kernel_ms = nullptr) {
   SMPLR_REQUIRE(B >= 0 && W > 0 && W <= 160 && P >= 1 && P <= 31 && K > 0 && K <= BIN_T * IPT_MAX,
                 "%s: bad sizes B=%d W=%d (max 160) P=%d (max 31) K=%d", fn, B, W, P, K);
   const bool with_loss = lo.loss != nullptr;
@@ -2089,6 +2093,22 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
                      reinterpret_cast<const int *>(base + ws.lstart_off),                                      \
                      reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, seg,          \
                      reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W), lo)
+  if (kernel_ms) {
+    hipEvent_t e0, e1;
+    SMPLR_HIP(hipEventCreate(&e0));
+    SMPLR_HIP(hipEventCreate(&e1));
+    hipExtLaunchKernelGGL(raster_fwd_kernel<false>, dim3(grid), dim3(RTS * NG), 0, as_stream(stream), e0, e1, 0,
+                          reinterpret_cast<const float4 *>(rec), reinterpret_cast<const int *>(base + ws.goff_off),
+                          reinterpret_cast<const int *>(base + ws.lstart_off),
+                          reinterpret_cast<const uint2 *>(base + ws.lrec_off), P, K, S, W, B, ntiles, seg,
+                          reinterpret_cast<short *>(arg), (unsigned)(((1u << 24) + W - 1) / W), lo);
+    SMPLR_LAUNCH_CHECK(fn);
+    SMPLR_HIP(hipEventSynchronize(e1));
+    SMPLR_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return 0;
+  }
   if (with_loss) SMPLR_RASTER_LAUNCH(true);
   else SMPLR_RASTER_LAUNCH(false);
 #undef SMPLR_RASTER_LAUNCH
@@ -2150,6 +2170,13 @@ int smplr_skin_vis_seg_fwd(const float *v_posed, const float *lbs_top4, const fl
                         K, workspace, rec, vslot, stream, sk);
   if (rc) return rc;
   return seg_raster_impl("smplr_skin_vis_seg_fwd", B, W, P, K, workspace, rec, seg, arg, stream);
+}
+
+int smplr_seg_raster_timed(int B, int W, int P, int K, const void *workspace, const float *rec, float *seg, int16_t *arg,
+                           float *kernel_ms, void *stream) {
+  SMPLR_REQUIRE(kernel_ms != nullptr, "smplr_seg_raster_timed: null kernel_ms");
+  return smplr::seg_raster_impl("smplr_seg_raster_timed", B, W, P, K, workspace, rec, seg, arg, stream, smplr::LossOut{},
+                                kernel_ms);
 }
 
 int smplr_seg_raster_ex(int B, int W, int P, int K, const void *workspace, const float *rec, const int32_t *labels,
