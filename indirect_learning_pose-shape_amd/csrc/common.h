@@ -40,6 +40,17 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int WAVE = 64;
 
+// Stores of tensors that nothing in the step reads again (verts, proj, mask, the scores): non-temporal, so that they
+// do not push the 54 MB of packed blend constants and the step's own intermediates out of the Infinity Cache
+// (the step moves 317 MB against its 256 MB): A/B on one box, default step 0.1298 / 0.1289 against 0.1307 / 0.1301 ms,
+// both heads 0.167 against 0.172.  -DSMPLR_PLAIN_OUT_STORES restores plain stores (tools/build_variant.sh).
+#ifdef SMPLR_PLAIN_OUT_STORES
+#define SMPLR_OUT_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define SMPLR_OUT_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+// (non-temporal LOADS of dseg, the step's one large read-once input, measured no gain: 0.1303 against 0.1298 ms)
+
 // In-kernel timelines (tools/probes/*_timeline.py).  Built with -DSMPLR_TL (make CXXFLAGS+=-DSMPLR_TL) a kernel that
 // declares SMPLR_TL_WAVE(buffer, waves-per-workgroup, workgroup) has one lane per wave stamp the shader clock into a
 // __device__ buffer (32 words per wave: 0 = entry, 28 = the 100 MHz wall clock, 29 = HW_ID, 30 = XCC_ID) at every

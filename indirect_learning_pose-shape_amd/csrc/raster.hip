@@ -206,8 +206,8 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       vv[q] = project_u(Y, c1, c3);
       vz[q] = Z;
       if (v < VP) {                                // (either output may be NULL: block-uniform)
-        if (sk.verts) { vo[v * 3 + 0] = X; vo[v * 3 + 1] = Y; vo[v * 3 + 2] = Z; }
-        if (sk.proj) { po[v * 3 + 0] = vu[q]; po[v * 3 + 1] = vv[q]; po[v * 3 + 2] = Z; }
+        if (sk.verts) { SMPLR_OUT_STORE(&vo[v * 3 + 0], X); SMPLR_OUT_STORE(&vo[v * 3 + 1], Y); SMPLR_OUT_STORE(&vo[v * 3 + 2], Z); }
+        if (sk.proj) { SMPLR_OUT_STORE(&po[v * 3 + 0], vu[q]); SMPLR_OUT_STORE(&po[v * 3 + 1], vv[q]); SMPLR_OUT_STORE(&po[v * 3 + 2], Z); }
       }
       __builtin_amdgcn_sched_barrier(0);          // one vertex at a time: seven T matrices at once do not fit the registers
     }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     vertex1 = s_any_empty && ref_compat && VP > 1;
     if (mask)                                      // (NULL with SKIN when the caller does not want it: block-uniform)
       for (int v = tid; v < VP; v += BIN_T)
-        mk[v] = (((vis[v >> 5] >> (v & 31)) & 1u) || (vertex1 && v == 1)) ? 1.0f : 500.0f;
+        SMPLR_OUT_STORE(&mk[v], (((vis[v >> 5] >> (v & 31)) & 1u) || (vertex1 && v == 1)) ? 1.0f : 500.0f);
   }
   SMPLR_TL_STAMP(7);
   float4 *Gn = G + (size_t)n * S;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
       if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
       } else if (c4 + 3 < C && (C & 3) == 0) {
-        *reinterpret_cast<float4 *>(so) = make_float4(v[0], v[1], v[2], v[3]);
+        SMPLR_OUT_STORE(reinterpret_cast<f32x4 *>(so), (f32x4{v[0], v[1], v[2], v[3]}));
       } else {
         for (int t = 0; t < 4; ++t)
           if (c4 + t < C) so[t] = v[t];

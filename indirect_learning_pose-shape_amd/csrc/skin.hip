@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(const float *__restrict__
     if (live) {
       if (verts) {
         float *o = verts + ((size_t)n * V + v) * 3;
-        o[0] = X; o[1] = Y; o[2] = Z;
+        SMPLR_OUT_STORE(&o[0], X); SMPLR_OUT_STORE(&o[1], Y); SMPLR_OUT_STORE(&o[2], Z);
       }
-      if (proj && sampled) {
+      if (proj && sampled) {                       // (default policy: the binning / silhouette kernels read it next)
         float *o = proj + ((size_t)n * VP + vp_idx) * 3;
         o[0] = project_u(X, c0, c2);
         o[1] = project_u(Y, c1, c3);
