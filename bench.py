@@ -80,15 +80,17 @@ def graph_time_ms(fn, reps, stream):
         with torch.cuda.graph(g):
             for _ in range(reps):
                 fn()
-        g.replay()
+        for _ in range(max(2, 100 // reps)):             # (>= 100 untimed calls: a settled clock, as for the headline)
+            g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = max(3, 60 // reps)
         e0.record(stream)
-        for _ in range(3):
+        for _ in range(nrep):
             g.replay()
         e1.record(stream)
         e1.synchronize()
-        return e0.elapsed_time(e1) / (3 * reps)
+        return e0.elapsed_time(e1) / (nrep * reps)
     except Exception:
         torch.cuda.synchronize()
         return event_time_ms(fn, reps, stream)
