@@ -292,3 +292,35 @@ def test_silhouette_hint_changes_nothing(layer, B):
     s2, a2 = ops._silh_fwd(proj, W, hint=torch.zeros_like(vmax))
     s3, a3 = ops._silh_fwd(proj, W, hint=torch.full_like(vmax, 1e-30))
     assert torch.equal(s0, s2) and torch.equal(a0, a2) and torch.equal(s0, s3) and torch.equal(a0, a3)
+
+
+def test_fused_loss_step_is_bit_reproducible_B128(smpl_model):
+    """BASELINE configs[2]'s batch through the fused-loss decoder with deterministic=True: per-pixel loss, statistics
+    and dx are bit for bit the same on every launch, also with other work and other batch sizes in between (the
+    allocator hands out different addresses); and the loss' row independence: rows computed 32 at a time equal the
+    rows of the full batch."""
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.focal_loss import softmax_focal_loss
+    B, W = 128, 48
+    x = t(make_x(B, W, seed=9))
+    dec = SMPLDecoder(smpl_model, img_wh=W, outputs=(), loss=softmax_focal_loss(2.0, True), deterministic=True)
+    lab = torch.randint(0, 32, (B, W, W), device=dev())
+    cot = t(np.random.default_rng(2).normal(0, 1, (B, W * W)) / (B * W * W))
+
+    def step(xs, ls, cs):
+        xg = xs.detach().requires_grad_(True)
+        out = dec(xg, ls)
+        (out["seg_loss"] * cs).sum().backward()
+        return out["seg_loss"].detach().clone(), xg.grad.clone()
+
+    ref = step(x, lab, cot)
+    for k in range(12):
+        if k % 3 == 0:
+            junk = [torch.full((1 << 22,), float("nan"), device=dev()) for _ in range(3)]
+            del junk
+            step(x[:40], lab[:40], cot[:40])
+        cur = step(x, lab, cot)
+        assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), "launch %d differs" % k
+    for lo in range(0, B, 32):
+        part = step(x[lo:lo + 32], lab[lo:lo + 32], cot[lo:lo + 32])
+        assert torch.equal(part[0], ref[0][lo:lo + 32]) and torch.equal(part[1], ref[1][lo:lo + 32])
