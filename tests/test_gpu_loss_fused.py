@@ -297,8 +297,8 @@ def test_silhouette_hint_changes_nothing(layer, B):
 def test_fused_loss_step_is_bit_reproducible_B128(smpl_model):
     """BASELINE configs[2]'s batch through the fused-loss decoder with deterministic=True: per-pixel loss, statistics
     and dx are bit for bit the same on every launch, also with other work and other batch sizes in between (the
-    allocator hands out different addresses); and the loss' row independence: rows computed 32 at a time equal the
-    rows of the full batch."""
+    allocator hands out different addresses); and row independence: the loss of rows computed 32 at a time equals the
+    full batch's rows bit for bit, their dx to rounding."""
     from ilps_amd.decoder import SMPLDecoder
     from ilps_amd.focal_loss import softmax_focal_loss
     B, W = 128, 48
@@ -323,4 +323,7 @@ def test_fused_loss_step_is_bit_reproducible_B128(smpl_model):
         assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]), "launch %d differs" % k
     for lo in range(0, B, 32):
         part = step(x[lo:lo + 32], lab[lo:lo + 32], cot[lo:lo + 32])
-        assert torch.equal(part[0], ref[0][lo:lo + 32]) and torch.equal(part[1], ref[1][lo:lo + 32])
+        assert torch.equal(part[0], ref[0][lo:lo + 32])
+        # (dx: the backward groups its partial sums by batch size - 24-row blocks at B = 128, 8-row blocks at B = 32 -
+        # so the rows agree to rounding, not bit for bit)
+        grad_close(part[1].cpu().numpy(), ref[1][lo:lo + 32].cpu().numpy(), 1e-5, "dx rows %d.." % lo)
