@@ -378,10 +378,12 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
 // each slice in halves with an LDS hand-over: 15.7 us.
 constexpr int B3_DEPTH = 5;
 
-__device__ __forceinline__ void blend3_bwd_tile(const float *__restrict__ dvp, const u32x4 *__restrict__ pk, int B,
-                                                int N3, int ktps, int nslices, int nmt, float *__restrict__ part,
-                                                int bid) {
+__global__ __launch_bounds__(256) void blend3_bwd_kernel(const float *__restrict__ dvp,
+                                                         const u32x4 *__restrict__ pk, int B, int N3,
+                                                         int ktps, int nslices, int nmt,
+                                                         float *__restrict__ part) {
   // XCD-aware map: the nmt mesh tiles of one column slice (same constant rows) share an XCD's L2.
+  const int bid = blockIdx.x;
   const int group = bid / (8 * nmt), within = bid % (8 * nmt);
   const int slice = group * 8 + (within & 7), mt = within >> 3;
   if (slice >= nslices) return;
@@ -480,32 +482,6 @@ __device__ __forceinline__ void blend3_bwd_tile(const float *__restrict__ dvp, c
   }
 }
 
-__global__ __launch_bounds__(256) void blend3_bwd_kernel(const float *__restrict__ dvp,
-                                                         const u32x4 *__restrict__ pk, int B, int N3,
-                                                         int ktps, int nslices, int nmt,
-                                                         float *__restrict__ part) {
-  blend3_bwd_tile(dvp, pk, B, N3, ktps, nslices, nmt, part, blockIdx.x);
-}
-
-// The GEMM tiles + the pose backward's CHAIN role in one launch (smplr_smpl_bwd): the first B workgroups take one mesh
-// each through pose_bwd_body<256, CHAIN> - the skinning partials' sums and the kinematic chain's backward, which need
-// nothing of this GEMM - and leave dR / d beta terms / dcam in `mid` for pose_bwd_tail_kernel; the others are the
-// GEMM's tiles.  Nothing is handed between workgroups.  A chain workgroup is one wave per SIMD at this kernel's
-// register count, so it shares a CU with a GEMM tile (one wave per SIMD as well): 2.7 us of chain and the skinning
-// partials' round trip leave the critical path between the GEMM and the tail.
-__global__ __launch_bounds__(256) void blend3_bwd_chain_kernel(const float *__restrict__ dvp,
-                                                               const u32x4 *__restrict__ pk, int B, int N3, int ktps,
-                                                               int nslices, int nmt, float *__restrict__ part,
-                                                               PoseBwdArgs a) {
-  __shared__ PoseLds lds1;
-  __shared__ float sJd[720];
-  if ((int)blockIdx.x < B) {                       // block-uniform
-    pose_bwd_body<256, POSE_BWD_CHAIN>(a, blockIdx.x, lds1, sJd);
-    return;
-  }
-  blend3_bwd_tile(dvp, pk, B, N3, ktps, nslices, nmt, part, (int)blockIdx.x - B);
-}
-
 // k-tiles per slice: about one workgroup per CU, and at most 60 slices so that pose_bwd sums a
 // mesh's partials with one batch of loads.
 Blend3BwdGeom blend3_bwd_geom(int B, int N3) {
@@ -528,16 +504,6 @@ int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B,
   hipLaunchKernelGGL(blend3_bwd_kernel, dim3(grid), dim3(256), 0, st, dv_posed,
                      reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
   SMPLR_LAUNCH_CHECK("blend3_bwd_kernel");
-  return 0;
-}
-
-int launch_blend3_bwd_chain(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
-                            const PoseBwdArgs &a, hipStream_t st) {
-  const Blend3BwdGeom g = blend3_bwd_geom(B, N3);
-  const int grid = B + ((g.nslices + 7) / 8) * 8 * g.nmt;
-  hipLaunchKernelGGL(blend3_bwd_chain_kernel, dim3(grid), dim3(256), 0, st, dv_posed,
-                     reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part, a);
-  SMPLR_LAUNCH_CHECK("blend3_bwd_chain_kernel");
   return 0;
 }
 

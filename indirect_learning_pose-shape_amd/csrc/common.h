@@ -98,10 +98,6 @@ struct Blend3BwdGeom { int nslices, ktps, nmt; size_t part_floats; };
 Blend3BwdGeom blend3_bwd_geom(int B, int N3);
 int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
                                hipStream_t st);
-// the same launch with the pose backward's chain role beside the GEMM tiles (pose_device.h: pose_bwd_body<.., CHAIN>)
-struct PoseBwdArgs;
-int launch_blend3_bwd_chain(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
-                            const PoseBwdArgs &a, hipStream_t st);
 int skin_bwd_nblk(int V);
 // The segmentation backward's per-row-block slot sums (raster.hip), which the skinning backward can gather
 // by vertex instead of reading a merged dproj: part (B, nsplit, SB_NWIN, SB_SLOTS, 2), vslot (B, VP) = the
