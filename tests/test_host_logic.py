@@ -185,3 +185,27 @@ def test_part_table_rejects_repeated_vertices():
         ops.build_part_table([0, 1, 2, 1], [0, 2, 4], None, 10, torch.device("cpu"))
     with pytest.raises(ValueError):
         ops.build_part_table([0, 1, 4], [0, 1, 3], 2, 10, torch.device("cpu"))      # 0 // 2 == 1 // 2
+
+
+def test_decoder_options_are_validated_without_a_gpu():
+    """SMPLDecoder(heads=, outputs=, loss=): argument errors surface at construction, before any kernel is touched."""
+    import pytest
+    from ilps_amd.decoder import SMPLDecoder
+    from ilps_amd.focal_loss import softmax_focal_loss
+    d = SMPLDecoder(None, img_wh=48)
+    assert d.heads == ("seg",) and d.outputs == ("verts", "projects", "mask") and d.loss is None
+    assert SMPLDecoder(None, with_silhouette=True).heads == ("seg", "silhouette")
+    s = SMPLDecoder(None, heads=("silhouette",), outputs=())
+    assert s.with_silhouette and s.outputs == ()
+    lf = softmax_focal_loss(2.0, True)
+    assert lf.gamma == 2.0 and lf.weight_classes is True
+    assert SMPLDecoder(None, loss=lf, outputs=()).loss is lf
+    for bad in (dict(heads=()), dict(heads=("seg", "depth")), dict(outputs=("seg",)),
+                dict(heads=("silhouette",), loss=lf), dict(loss=lambda a, b: a),
+                dict(heads=("silhouette",), vertex_sampling=5)):
+        with pytest.raises(ValueError):
+            SMPLDecoder(None, **bad)
+    # the HIP path has no CPU fallback: a CPU tensor is refused, not silently computed elsewhere
+    import torch
+    with pytest.raises(RuntimeError):
+        d(torch.zeros(2, 86))
