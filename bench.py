@@ -584,6 +584,8 @@ def main():
     ap.add_argument("--step", default="default",
                     choices=["default", "seg_only", "fused_loss", "unfused_loss", "both_heads", "silhouette_only"],
                     help="time a variant of the decoder step (profiling); the headline is `default`")
+    ap.add_argument("--min-warmup", type=int, default=200,
+                    help="floor of the untimed warm-up steps (0 for counter passes, where every launch is serialised)")
     ap.add_argument("--graph-steps", type=int, default=10,
                     help="graph mode: whole steps captured per graph launch (cut to a divisor of --steps)")
     ap.add_argument("--streams", type=int, default=1,
@@ -719,9 +721,9 @@ def main():
             gsteps = 1
             run = step
             torch.cuda.synchronize()
-    nrun, nwarm = args.steps // gsteps, -(-max(args.warmup, 200) // gsteps)   # launches of `run` = steps / gsteps
+    nrun, nwarm = args.steps // gsteps, -(-max(args.warmup, args.min_warmup) // gsteps)   # launches of `run` = steps / gsteps
 
-    # untimed: the W warm-up steps asked for, and at least 200 (30 ms of replays) so that the GPU's clock has settled
+    # untimed: the W warm-up steps asked for, and at least --min-warmup (default 200: 30 ms of replays) so that the GPU's clock has settled
     # before the timed window (with 10 the first window of 50 steps read 5 % over the nine that followed it)
     for _ in range(nwarm):
         run()

@@ -626,8 +626,17 @@ __device__ __forceinline__ float max8_dpp(float v) {
 // which spares it its own search for one (smplr_silh_fwd_hint).
 struct LossOut { const int *labels; const float *class_w; float gamma; float *loss; float4 *stats; float *vmax; };
 
+// (amdgpu_num_sgpr: two blocks of 16 waves share a CU, 8 waves per SIMD, and that holds up to 80 scalar registers per
+// wave only - 800 per SIMD, allotted in 16s, 16 more per wave for the trap handler the runtime installs - although the
+// compiler's own table reports "Occupancy: 8" up to 102: a build of the LOSS variant with 83 ran ONE block per CU and
+// took 46.6 us instead of 37.3 with fewer instructions (SQ_WAVE_CYCLES / SQ_BUSY_CYCLES halved).)
+#ifdef SMPLR_RASTER_NO_SGPR_CAP
+#define SMPLR_RASTER_SGPRS
+#else
+#define SMPLR_RASTER_SGPRS __attribute__((amdgpu_num_sgpr(80)))
+#endif
 template <bool LOSS>
-__global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__restrict__ G,
+__global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel(const float4 *__restrict__ G,
                                                              const int *__restrict__ goff,
                                                              const int *__restrict__ lstart,
                                                              const uint2 *__restrict__ lrec, int P, int K,
@@ -823,6 +832,9 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
   // on the score bits (scores are >= 0, so the integer order is the float order) whose return value tells the
   // lane whether it raised the slot; the slot read back tells it whether a later lane of the same step raised
   // it further.  LDS operations of one wave execute in order, so no barrier separates merge and write-out.
+  // LOSS: what the pixel of merge step `it` needs for its loss, in all 8 of its lanes; finished after the loop
+  float den_[NIT], st_[NIT], eg_[NIT];
+  unsigned po_[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = it * (RTS * NG) + tid;
@@ -873,35 +885,24 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
     }
     const int qq = tile * RTS + pl;
-    float ls = 0.0f, inv = 0.0f, k1 = 0.0f, gbu = 0.0f;
     if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
-      const float den = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
+      den_[it] = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
       const int t = lab[it];
       const float vt = (t & 2) ? ((t & 1) ? v[3] : v[2]) : ((t & 1) ? v[1] : v[0]);
-      const float st = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);   // the labelled class' score in all 8 lanes (+ exact zeros)
-      // (v_rcp_f32 / v_log_f32: 1 ulp and ~1e-7 absolute in log2 on p in [1e-7, 1) - far inside the loss head's 1e-4
-      // bar - where the IEEE division and logf() were a fifth of this phase's instructions)
-      inv = __builtin_amdgcn_rcpf(den);
-      const float sm = __expf(st) * inv;
-      const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
-      const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
-      const float om = 1.0f - p, lg = __logf(p), w = wlab[it];
-      const float pg = pow_gamma(om, lo.gamma);
-      ls = (unsigned)t < 32u ? pg * ((-lg) * w) : 0.0f;                          // :18, :41, :43-44
-      // d loss / d softmax_t (the clip passes gradient on [eps, 1 - eps] only) x softmax_t: with it
-      // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
-      k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
-      // what the background contributes to every channel's gradient where the clip's gate is open, per unit of k1
-      gbu = a[0] ? ((t == 0 ? 1.0f : 0.0f) - __expf(v[0]) * inv) : 0.0f;         // (lane c4 == 0: v[0] = background)
+      st_[it] = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);      // the labelled class' score in all 8 lanes (+ exact zeros)
+      // the background's exp (what it contributes to every channel's gradient) where the clip's gate is open, else a
+      // negative number, from the pixel's lane 0 to its lanes 0 .. 3 (quad_perm 0,0,0,0)
+      const float eg = a[0] ? __expf(v[0]) : -1.0f;
+      eg_[it] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(eg), 0x00, 0xF, 0xF, false));
     }
-    if (qq < npix && c4 < C) {
+    unsigned po = ~0u;
+    if (qq < npix) {
       const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
-      const unsigned po = (unsigned)((W - 1 - rr) * W + cc);     // rows flipped (:68); mesh base + 32-bit offset
+      po = (unsigned)((W - 1 - rr) * W + cc);              // rows flipped (:68); mesh base + 32-bit offset
+    }
+    if (LOSS) po_[it] = po;
+    if (qq < npix && c4 < C) {
       if (lo.vmax && c4 == 0) lo.vmax[(size_t)n * npix + po] = vmx;
-      if (LOSS && c4 == 0) {
-        lo.loss[(size_t)n * npix + po] = ls;
-        lo.stats[(size_t)n * npix + po] = make_float4(k1 * inv, k1 * gbu, k1, __int_as_float(lab[it]));
-      }
       float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
       if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
       } else if (c4 + 3 < C && (C & 3) == 0) {
@@ -913,6 +914,43 @@ __global__ __launch_bounds__(RTS * NG) void raster_fwd_kernel(const float4 *__re
       short4 o4;
       o4.x = a[0]; o4.y = a[1]; o4.z = a[2]; o4.w = a[3];
       *reinterpret_cast<short4 *>(arg + (size_t)n * npix * 32 + (po * 32u + (unsigned)c4)) = o4;
+    }
+  }
+  if (LOSS) {
+    // The per-pixel end of the loss (a dozen transcendental and clip steps) once for all merge steps of the lane: lane
+    // `it` of a pixel's 8 finishes the pixel of step `it`, so the NIT pixels share one pass of the instructions
+    // instead of running them NIT times in 8 lanes each.
+    static_assert(NIT <= 4, "the background's lane reaches its quad only");
+    float den = den_[0], st = st_[0], eg = eg_[0], w = wlab[0];
+    int t = lab[0];
+    unsigned po = po_[0];
+#pragma unroll
+    for (int it = 1; it < NIT; ++it) {
+      if (sub == it) {
+        den = den_[it]; st = st_[it]; eg = eg_[it]; w = wlab[it];
+        t = lab[it];
+        po = po_[it];
+      }
+    }
+    // (v_rcp_f32 / v_log_f32: 1 ulp and ~1e-7 absolute in log2 on p in [1e-7, 1) - far inside the loss head's 1e-4
+    // bar - where the IEEE division and logf() were a fifth of this phase's instructions; the raw instruction, not
+    // __logf(): p >= 1e-7 is never denormal, and the library form spends 12 instructions on that case and on a
+    // two-term product with ln 2)
+    const float inv = __builtin_amdgcn_rcpf(den);
+    const float sm = __expf(st) * inv;
+    const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
+    const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
+    const float om = 1.0f - p, lg = __builtin_amdgcn_logf(p) * 0.6931471806f;
+    const float pg = pow_gamma(om, lo.gamma);
+    const float ls = (unsigned)t < 32u ? pg * ((-lg) * w) : 0.0f;              // :18, :41, :43-44
+    // d loss / d softmax_t (the clip passes gradient on [eps, 1 - eps] only) x softmax_t: with it
+    // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
+    const float k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
+    // what the background contributes to every channel's gradient where the clip's gate is open, per unit of k1
+    const float gbu = eg >= 0.0f ? ((t == 0 ? 1.0f : 0.0f) - eg * inv) : 0.0f;
+    if (sub < NIT && po != ~0u) {
+      lo.loss[(size_t)n * npix + po] = ls;
+      lo.stats[(size_t)n * npix + po] = make_float4(k1 * inv, k1 * gbu, k1, __int_as_float(t));
     }
   }
   SMPLR_TL_STAMP(6);

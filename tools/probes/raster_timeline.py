@@ -18,10 +18,17 @@ NAMES = ["entry", "requests issued", "barrier (records in LDS)", "row tables bui
 def main():
     B, W = 128, 48
     dev = torch.device("cuda", 0)
-    dec = SMPLDecoder(None, img_wh=W)
     x = torch.tensor(bench.make_x(B, W, 11), device=dev)
-    for it in range(3):
-        dec(x)
+    if os.environ.get("TL_LOSS"):                      # the kernel with the loss head as its epilogue
+        from ilps_amd.focal_loss import softmax_focal_loss
+        dec = SMPLDecoder(None, img_wh=W, outputs=(), loss=softmax_focal_loss(2.0, True))
+        labels = torch.randint(0, 32, (B, W, W), device=dev, dtype=torch.int32)
+        for it in range(3):
+            dec(x, labels)
+    else:
+        dec = SMPLDecoder(None, img_wh=W)
+        for it in range(3):
+            dec(x)
     torch.cuda.synchronize()
     t = read_stamps("raster", 1152, 16)
     d = (t - t[..., :1]) & 0xFFFFFFFF

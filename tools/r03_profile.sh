@@ -28,7 +28,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   if [ "$MODE" = traffic ] && [ $i -le 2 ]; then continue; fi
-  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_step_$i -- python3 $R/bench.py --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/pmc_step_$i.log 2>&1; echo "pmc step pass $i rc=$?") || exit 1
+  (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_step_$i -- python3 $R/bench.py --steps 3 --warmup 2 --min-warmup 20 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/pmc_step_$i.log 2>&1; echo "pmc step pass $i rc=$?") || exit 1
 done
 for V in seg_only fused_loss unfused_loss both_heads silhouette_only; do
   (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$V -- python3 $R/bench.py --step $V --steps 20 --warmup 5 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/rocprof_$V.log 2>&1; echo "rocprof($V) rc=$?") || exit 1
@@ -36,7 +36,7 @@ for V in seg_only fused_loss unfused_loss both_heads silhouette_only; do
   j=0
   for SET in "FETCH_SIZE" "WRITE_SIZE"; do
     j=$((j+1))
-    (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_${V}_$j -- python3 $R/bench.py --step $V --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/pmc_${V}_$j.log 2>&1; echo "pmc $V pass $j rc=$?") || exit 1
+    (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_${V}_$j -- python3 $R/bench.py --step $V --steps 3 --warmup 2 --min-warmup 20 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/pmc_${V}_$j.log 2>&1; echo "pmc $V pass $j rc=$?") || exit 1
   done
 done
 if [ "$MODE" != traffic ]; then
