@@ -49,6 +49,8 @@ __device__ unsigned g_tl_bin[TL_BIN_WG * (BIN_T / 64) * 32];
 __device__ unsigned g_tl_segbwd[TL_SEGBWD_WG * 12 * 32];
 constexpr int TL_RASTER_WG = 1152;
 __device__ unsigned g_tl_raster[TL_RASTER_WG * 16 * 32];
+constexpr int TL_SILHPX_WG = 256;
+__device__ unsigned g_tl_silhpx[TL_SILHPX_WG * 16 * 32];
 #endif
 constexpr int IPT_MAX = 8;           // part-table slots per bin thread: K <= 8192
 
@@ -1703,6 +1705,7 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
   __shared__ int s_wave[SF_T / 64];
   __shared__ int s_nout;
   const int n = blockIdx.x, tid = threadIdx.x;
+  SMPLR_TL_WAVE(g_tl_silhpx, 16, blockIdx.x * gridDim.y + blockIdx.y, TL_SILHPX_WG)
   const int GW = W + 2 * SM, GWP = L.GWP, WP = L.WP, cells = GW * GWP;        // GW <= 64
   char *lds = reinterpret_cast<char *>(s_cnt);
   signed char *gtab = reinterpret_cast<signed char *>(lds + L.gtab);
@@ -1724,6 +1727,7 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
   if (tid < GW) rowmask[tid] = 0ull;
   if (tid == 0) s_nout = 0;
   __syncthreads();
+  SMPLR_TL_STAMP(1);
   int pc[IPT_MAX], rank[IPT_MAX];
 #pragma unroll
   for (int j = 0; j < IPT_MAX; ++j) {
@@ -1749,35 +1753,41 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
     }
   }
   __syncthreads();
-  // exclusive scan of the counts: s_cnt[e] = start of cell e, s_cnt[cells] = vertices inside the window;
-  // the occupied cells set their bit of the row words
-  const int ept = (cells + SF_T - 1) / SF_T;
-  const int e0 = tid * ept, e1 = min(cells, e0 + ept);
+  SMPLR_TL_STAMP(2);
+  // exclusive scan of the counts: s_cnt[e] = start of cell e, s_cnt[cells] = vertices inside the window; the
+  // occupied cells set their bit of the row words.  Thread (row tid / 16, segment tid % 16) takes the segment's cells
+  // of its row - row-major order is thread order, and no cell index is ever divided by the row length (GW <= 64 rows)
+  const int by = tid >> 4, bs = tid & 15;
+  const int cpt = (GWP + 15) >> 4;
+  const int bx0 = bs * cpt, bx1 = by < GW ? min(GWP, bx0 + cpt) : bx0;
   int lc = 0;
-  for (int e = e0; e < e1; ++e) {
-    const int c = s_cnt[e];
-    lc += c;
-    if (c) {
-      const int y = e / GWP;
-      atomicOr(&rowmask[y], 1ull << (e - y * GWP));
+  {
+    unsigned long long bits = 0ull;
+    for (int x = bx0; x < bx1; ++x) {
+      const int c = s_cnt[by * GWP + x];
+      lc += c;
+      if (c) bits |= 1ull << x;
     }
+    if (bits) atomicOr(&rowmask[by], bits);
   }
   int tot_v;
   int run_v = block_excl_scan(lc, s_wave, &tot_v);          // (its barriers also publish the row words)
-  for (int e = e0; e < e1; ++e) {
-    const int c = s_cnt[e];
-    s_cnt[e] = run_v;
+  for (int x = bx0; x < bx1; ++x) {
+    const int c = s_cnt[by * GWP + x];
+    s_cnt[by * GWP + x] = run_v;
     run_v += c;
   }
   if (tid == 0) s_cnt[cells] = tot_v;
   const int nout = s_nout;
   // offsets to the nearest occupied cell of each row (the pad column is never read)
-  for (int e = tid; e < GW * GW; e += SF_T) {
-    const int y = e / GW, x = e - y * GW;
-    const unsigned long long m = rowmask[y];
-    gtab[y * GWP + x] = (signed char)(m ? nearest_bit1(m, x) : SPX_EMPTY);
+  if (by < GW) {
+    const unsigned long long m = rowmask[by];
+    const int gpt = (GW + 15) >> 4;
+    for (int x = bs * gpt; x < min(GW, bs * gpt + gpt); ++x)
+      gtab[by * GWP + x] = (signed char)(m ? nearest_bit1(m, x) : SPX_EMPTY);
   }
   __syncthreads();
+  SMPLR_TL_STAMP(3);
   // placement by rank
 #pragma unroll
   for (int j = 0; j < IPT_MAX; ++j) {
@@ -1788,6 +1798,14 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
     if (dst >= 0) sRec[dst] = make_float4(pu[j], pv[j], __int_as_float(v), 0.0f);
   }
   __syncthreads();
+  SMPLR_TL_STAMP(4);
+#ifdef SMPLR_TL
+  int tl_k = 0;
+  unsigned tl_a = 0, tl_b = 0, tl_c = 0, tl_t0 = 0, tl_t1 = 0, tl_t2 = 0;     // clocks in steps (1)-(2), (3), the ranges
+#define SMPLR_TL_CLK(x) x = (unsigned)clock64()
+#else
+#define SMPLR_TL_CLK(x)
+#endif
   // ---- pixels: a wave takes 8 x 8 tiles, handed out through a counter (tiles on the outline cost more)
   const int lane = tid & 63;
   const int tpr = (W + SPX_TILE - 1) / SPX_TILE, ntile = tpr * tpr;
@@ -1820,6 +1838,7 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
     const int cx = c + SM, cy = r + SM;
     // this wave's candidate map, one word per cell row.  The lanes talk to each other through it, so every access
     // is an atomic operation to the compiler (with plain accesses it forwards a lane's own zero to its read)
+    SMPLR_TL_CLK(tl_t0);
     __hip_atomic_store(&ubm[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     unsigned long long best = own[r * WP + c];             // (d^2 bits << 32) | vertex index; ~0: own cell empty
     unsigned long long rows = 0ull;
@@ -1870,31 +1889,51 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
         rows = 0ull;
       }
     }
+    SMPLR_TL_CLK(tl_t1);
     // (3) A cell (x, y) is a candidate iff max(|x - cx| - 0.5, 0)^2 + max(|y - cy| - 0.5, 0)^2 <= lim, i.e. row by
-    // row |y - cy| <= 0.5 + sqrt(lim) and |x - cx| <= 0.5 + sqrt(lim - dym^2) (1e-4 covers the approximate roots)
+    // row |y - cy| <= 0.5 + sqrt(lim) and |x - cx| <= 0.5 + sqrt(lim - dym^2) (1e-4 covers the approximate roots).
+    // The lanes OR their intervals into the wave's map; the occupied cells are selected when the map is read back.
     if (lim >= 0.0f) {
       const int yr = (int)(__builtin_amdgcn_sqrtf(lim) + 0.5001f);
       const int ylo = max(0, cy - yr), yhi = min(GW - 1, cy + yr);
-      unsigned long long keep = ~((1ull << ylo) - 1ull);
-      if (yhi < 63) keep &= (2ull << yhi) - 1ull;
-      rows &= keep;
-    } else {
-      rows = 0ull;
+      if (rows == ~0ull) {
+        // (2'): every row in reach, one after the other: a row whose NEAREST occupied cell (one byte of the offset
+        // table) lies outside the row's interval holds no candidate and costs a dozen instructions
+        const signed char *g = gtab + ylo * GWP + cx;
+        for (int y = ylo; y <= yhi; ++y, g += GWP) {
+          const int off = *g;
+          const float dym = fmaxf((float)abs(y - cy) - 0.5f, 0.0f);
+          const float rem = lim - dym * dym;
+          if (rem < 0.0f) continue;
+          const int w = (int)(__builtin_amdgcn_sqrtf(rem) + 0.5001f);
+          if (abs(off) > w) continue;                       // (an empty row's entry is 127: beyond any radius)
+          const int xlo = max(0, cx - w), xhi = min(GW - 1, cx + w);
+          unsigned long long m = ~((1ull << xlo) - 1ull);
+          if (xhi < 63) m &= (2ull << xhi) - 1ull;
+          atomicOr(&ubm[y], m);
+        }
+      } else {
+        unsigned long long keep = ~((1ull << ylo) - 1ull);
+        if (yhi < 63) keep &= (2ull << yhi) - 1ull;
+        rows &= keep;
+        while (rows) {                                      // this lane's rows: its candidate cells into the wave's map
+          const int y = __ffsll((long long)rows) - 1;
+          rows &= rows - 1ull;
+          const float dym = fmaxf((float)abs(y - cy) - 0.5f, 0.0f);
+          const float rem = lim - dym * dym;
+          if (rem < 0.0f) continue;
+          const int w = (int)(__builtin_amdgcn_sqrtf(rem) + 0.5001f);
+          const int xlo = max(0, cx - w), xhi = min(GW - 1, cx + w);
+          unsigned long long m = ~((1ull << xlo) - 1ull);
+          if (xhi < 63) m &= (2ull << xhi) - 1ull;
+          atomicOr(&ubm[y], m);
+        }
+      }
     }
-    while (rows) {                                          // this lane's rows: its candidate cells into the wave's map
-      const int y = __ffsll((long long)rows) - 1;
-      rows &= rows - 1ull;
-      const float dym = fmaxf((float)abs(y - cy) - 0.5f, 0.0f);
-      const float rem = lim - dym * dym;
-      if (rem < 0.0f) continue;
-      const int w = (int)(__builtin_amdgcn_sqrtf(rem) + 0.5001f);
-      const int xlo = max(0, cx - w), xhi = min(GW - 1, cx + w);
-      unsigned long long m = rowmask[y] & ~((1ull << xlo) - 1ull);
-      if (xhi < 63) m &= (2ull << xhi) - 1ull;
-      if (m) atomicOr(&ubm[y], m);
-    }
+    SMPLR_TL_CLK(tl_t2);
     // LDS operations of one wave execute in order: the map is complete when lane y reads row y's word
     unsigned long long um = __hip_atomic_load(&ubm[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    um &= lane < GW ? rowmask[lane] : 0ull;
     while (__ballot(um != 0ull)) {
       // lane y: the first run of consecutive candidate cells of row y = one contiguous range of records
       int i0 = 0, i1 = 0;
@@ -1927,9 +1966,22 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
       *reinterpret_cast<float2 *>(out + o * 2) = make_float2(1.0f - score, score);
       arg_out[o] = pos;
     }
+#ifdef SMPLR_TL
+    tl_a += tl_t1 - tl_t0; tl_b += tl_t2 - tl_t1; tl_c += (unsigned)clock64() - tl_t2;
+    if (tl__ && tl_k < 6) {                                 // per tile: its index and the clock at its end
+      tl__[8 + 2 * tl_k] = (unsigned)tile;
+      tl__[9 + 2 * tl_k] = (unsigned)clock64();
+    }
+    ++tl_k;
+#endif
   }
+  SMPLR_TL_STAMP(5);
+#ifdef SMPLR_TL
+  if (tl__) { tl__[6] = (unsigned)tl_k; tl__[20] = tl_a; tl__[21] = tl_b; tl__[22] = tl_c; }
+#endif
 #undef SMPLR_SPX_RANGE
 #undef SMPLR_SPX_KEY
+#undef SMPLR_TL_CLK
 }
 
 // DET: the per-vertex sums as 64-bit fixed point (see seg_flush_det): bit-reproducible whatever the order in which
@@ -2388,4 +2440,5 @@ int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg, co
 SMPLR_TL_EXPORT(bin, smplr::g_tl_bin, smplr::TL_BIN_WG * (smplr::BIN_T / 64) * 32)
 SMPLR_TL_EXPORT(segbwd, smplr::g_tl_segbwd, smplr::TL_SEGBWD_WG * 12 * 32)
 SMPLR_TL_EXPORT(raster, smplr::g_tl_raster, smplr::TL_RASTER_WG * 16 * 32)
+SMPLR_TL_EXPORT(silhpx, smplr::g_tl_silhpx, smplr::TL_SILHPX_WG * 16 * 32)
 #endif

@@ -10,6 +10,7 @@ cp $S/eager_kernel_stats.csv $D/${P}_eager_kernel_stats.csv
 cp $S/default_kernel_stats.csv $D/${P}_default_bench_kernel_stats.csv
 cp $S/pmc_step_sq.txt $D/${P}_pmc_step_sq_counters.txt
 cp $S/batch_sweep.txt $D/${P}_batch_sweep.txt
+[ -f $S/step_variants.txt ] && cp $S/step_variants.txt $D/${P}_step_variants.txt
 for V in seg_only fused_loss unfused_loss both_heads silhouette_only; do
   cp $S/${V}_kernel_stats.csv $D/${P}_${V}_kernel_stats.csv
   PMC_TRAFFIC_NAME=${P}_traffic_${V}.json python tools/pmc_traffic.py $S/pmc_${V}_1 $S/pmc_${V}_2

@@ -42,6 +42,8 @@ done
 if [ "$MODE" != traffic ]; then
 python tools/pmc_summary.py $O/pmc_step_1 $O/pmc_step_2 > $O/pmc_step_sq.txt
 for b in 32 128 512 2048; do timeout -k 10 200 python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-breakdown --no-train-leg 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B=%d' % $b, l['value'], l['ms_per_step'])"; done > $O/batch_sweep.txt; cat $O/batch_sweep.txt
+# the step variants with the headline's timing method: variant, meshes/s, ms per step (first window), min / median / max of ten windows
+for V in default seg_only fused_loss unfused_loss both_heads silhouette_only; do timeout -k 10 200 python bench.py --step $V --steps 50 --no-cpu-baseline --no-breakdown --no-train-leg 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=l['ms_per_step_windows']; print('$V', l['value'], l['ms_per_step'], w['min'], w['median'], w['max'])"; done > $O/step_variants.txt; cat $O/step_variants.txt
 fi
 # keep only the CSVs (the rocprofv3 output dirs also hold large databases)
 find $O -name "*.db" -delete 2>/dev/null; du -sh $O
