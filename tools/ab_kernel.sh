@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"; PKG=indirect_learning_pose-shape_amd; K=$1; shift
 cp $PKG/libsmplraster_hip.so $PKG/lib_keep.so
 for v in "$@"; do
   cp $PKG/lib_$v.so $PKG/libsmplraster_hip.so; rm -rf gpurun_out/abk_$v
-  (cd /tmp && TMPDIR=/tmp timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/abk_$v -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --mode eager --no-cpu-baseline --no-breakdown > /dev/null 2>&1)
+  (cd /tmp && TMPDIR=/tmp timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/abk_$v -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > /dev/null 2>&1)
   python3 -c "
 import csv,glob
 f=glob.glob('gpurun_out/abk_$v/*/*_kernel_stats.csv')[0]
