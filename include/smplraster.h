@@ -40,8 +40,8 @@ extern "C" {
 
 int smplr_abi_version(void);
 const char *smplr_last_error(void);
-/* sha256 (64 hex digits) over the sources this library was built from - csrc/*.hip, csrc/*.h (sorted by name) and
- * this header, concatenated; the host side recomputes it from the files beside the library and refuses a stale
+/* sha256 (64 hex digits) over the sources this library was built from - the .hip and .h files of csrc/ (sorted by
+ * name) and this header, concatenated; the host side recomputes it from the files beside the library and refuses a stale
  * library (`_lib.load`).  No reference counterpart: the reference ships no compiled code.                      */
 const char *smplr_build_id(void);
 

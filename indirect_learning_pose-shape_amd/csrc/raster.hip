@@ -2195,8 +2195,8 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
     SMPLR_LAUNCH_CHECK(fn);
     SMPLR_HIP(hipEventSynchronize(e1));
     SMPLR_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
   }
   if (with_loss) SMPLR_RASTER_LAUNCH(true);
