@@ -132,9 +132,12 @@ __global__ __launch_bounds__(256) void coef3_pack_kernel(const float *__restrict
 // the first round trip, 252 MFMAs and the drain of 10.6 MB of output.  Rejected on the way (same
 // numerics): the constant shared through LDS with each wave fetching a quarter (16.4 us), eight
 // waves splitting K in pairs with an LDS hand-over (15.4 us).
-constexpr int F3_DEPTH = 3;
+// (two k-tiles ahead and at most 256 registers: TWO workgroups per CU, so that one's first round trip and output drain
+// hide under the other's loop - what counts once the grid is several rounds deep: B = 2 048 143.6 -> 136.4 us, and
+// 13.0 -> 12.4 us at B = 128; three ahead needed 308 registers, one wave per SIMD)
+constexpr int F3_DEPTH = 2;
 
-__global__ __launch_bounds__(256) void blend3_fwd_kernel(const u32x4 *__restrict__ coef3,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void blend3_fwd_kernel(const u32x4 *__restrict__ coef3,
                                                          const u32x4 *__restrict__ pk,
                                                          const float *__restrict__ vt, int B, int N3,
                                                          float *__restrict__ out) {
@@ -376,9 +379,12 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
 // pose_bwd (fused path) or blend_bwd_reduce_kernel: deterministic, no atomics.
 // Measured (B = 128): 14 us against 18.3 us for the fp32 matrix-core kernel; eight waves splitting
 // each slice in halves with an LDS hand-over: 15.7 us.
-constexpr int B3_DEPTH = 5;
-
-__global__ __launch_bounds__(256) void blend3_bwd_kernel(const float *__restrict__ dvp,
+// Two builds of the loop: B3_DEPTH k-tiles in flight ahead of the one being multiplied.  Five (288 registers, one
+// workgroup per CU) when the grid is several rounds deep and the constant streams from L2 at its limit; two (190
+// registers, amdgpu_waves_per_eu 2: TWO workgroups per CU, one's first round trip and partial stores under the other's
+// loop) below 512 meshes - B = 128: 12.1 us against 13.1, B = 512: 47.7 / 47.7, B = 2 048: 200.8 against 182.5.
+template <int B3_DEPTH, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void blend3_bwd_kernel(const float *__restrict__ dvp,
                                                          const u32x4 *__restrict__ pk, int B, int N3,
                                                          int ktps, int nslices, int nmt,
                                                          float *__restrict__ part) {
@@ -501,8 +507,12 @@ int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B,
                                hipStream_t st) {
   const Blend3BwdGeom g = blend3_bwd_geom(B, N3);
   const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
-  hipLaunchKernelGGL(blend3_bwd_kernel, dim3(grid), dim3(256), 0, st, dv_posed,
-                     reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
+  if (B < 512)
+    hipLaunchKernelGGL((blend3_bwd_kernel<2, 2>), dim3(grid), dim3(256), 0, st, dv_posed,
+                       reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
+  else
+    hipLaunchKernelGGL((blend3_bwd_kernel<5, 1>), dim3(grid), dim3(256), 0, st, dv_posed,
+                       reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
   SMPLR_LAUNCH_CHECK("blend3_bwd_kernel");
   return 0;
 }

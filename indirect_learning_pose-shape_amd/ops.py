@@ -882,6 +882,14 @@ class DecoderOpts:
     loss: Optional[tuple] = None
 
 
+# Batch from which the decoder's forward runs the pose kernel and the blend GEMM as two launches instead of one: the
+# single launch (pose chain hidden under the GEMM, coefficient rows staged in 116 KB of LDS) wins while the grid is one
+# round of workgroups - B = 128: 17.3 us against 7.1 + 13.0 - and loses once it is many, because that LDS allows one
+# workgroup per CU where the plain GEMM fits two: B = 512: 52.4 against 7.2 + 42.1, B = 2 048: 191 against 9.2 + 136.4
+# (tools/probes/blend_big.py).  Bit-identical either way.
+POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "512"))
+
+
 class DecoderFn(torch.autograd.Function):
     """The model.py:108-118 chain as ONE autograd node.
 
@@ -966,9 +974,10 @@ class DecoderFn(torch.autograd.Function):
         def run(lo, hi):
             xs = x[lo:hi]
             n = hi - lo
-            if consts.blend3_fwd is not None:
+            if consts.blend3_fwd is not None and n < POSE_BLEND_SPLIT_B:
                 _pose_blend_fwd(xs, num_cam, consts, out=(Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]), v_posed=v_posed[lo:hi])
             else:
+                # (also the bf16x3 constants at large batch: the same bits from two launches, see POSE_BLEND_SPLIT_B)
                 coef = _pose_fwd(xs, num_cam, consts, out=(None, Rs[lo:hi], J[lo:hi], A[lo:hi], Jt[lo:hi]))[0]
                 _blend_fwd(coef, consts, n, out=v_posed[lo:hi])
             if fuse_skin and (loss_spec is not None or vmax is not None):

@@ -334,8 +334,9 @@ def test_deterministic_rasteriser_ops_and_scaling(layer_inputs=None):
 
 def test_global_batch_1024_row_independence(smpl_model):
     """configs[4]'s GLOBAL batch (1 024 meshes) on one GPU: eight 128-mesh groups of the blend GEMM, the 8-row form
-    of the segmentation backward (B >= 512), one silhouette workgroup per mesh: every row must equal the same row
-    computed in a batch of 32 (forward bit for bit, gradient to rounding), and the gradient must be finite."""
+    of the segmentation backward (B >= 512), the pose kernel and the blend GEMM as two launches (ops.POSE_BLEND_SPLIT_B),
+    one silhouette workgroup per mesh: every row must equal the same row computed in a batch of 32 (one launch for pose
+    + blend; forward bit for bit, gradient to rounding), and the gradient must be finite."""
     from ilps_amd.decoder import SMPLDecoder
     W, B = 48, 1024
     x = make_x(B, W, seed=1024)
@@ -354,6 +355,22 @@ def test_global_batch_1024_row_independence(smpl_model):
         for k in ("verts", "mask", "seg", "silhouette"):
             assert torch.equal(o2[k], out[k][lo:lo + 32]), "%s rows %d.." % (k, lo)
         grad_close(xg.grad[lo:lo + 32].cpu().numpy(), xs.grad.cpu().numpy(), 1e-4, "dx rows %d.." % lo)
+
+
+def test_pose_and_blend_in_one_launch_or_two(smpl_model, monkeypatch):
+    """The decoder's forward runs pose + blend as one launch below ops.POSE_BLEND_SPLIT_B meshes and as two from there
+    on: the same bits either way (threshold moved under a small batch instead of running a large one)."""
+    from ilps_amd import ops
+    from ilps_amd.decoder import SMPLDecoder
+    B, W = 9, 48
+    x = t(make_x(B, W, seed=77))
+    dec = SMPLDecoder(smpl_model, img_wh=W)
+    with torch.no_grad():
+        one = dec(x)
+        monkeypatch.setattr(ops, "POSE_BLEND_SPLIT_B", 4)
+        two = dec(x)
+    for k in ("verts", "projects", "mask", "seg", "J_transformed"):
+        assert torch.equal(one[k], two[k]), k
 
 
 def test_decoder_step_replays_from_a_hip_graph(smpl_model):
