@@ -3,6 +3,11 @@
 # rebuilds the JSON files bench.py reads (stamped with the measured library's build id, taken from the run's bench
 # line):  bash tools/collect_profiles_r03.sh TAG [PREFIX]      (e.g. r03a r03)
 TAG=$1; P=${2:-r03}; S=gpurun_out/$TAG; D=profiles
+# a tag used twice leaves two runs' files side by side in the merged directory: refuse to mix them
+for d in $S/pmc_*/ $S/prof_*/; do
+  n=$(ls $d/*/*_agent_info.csv 2>/dev/null | wc -l)
+  if [ "$n" -gt 1 ]; then echo "collect: $d holds $n runs (tag reused?) - rerun tools/r03_profile.sh under a fresh tag"; exit 1; fi
+done
 BID=$(python -c "import json; print(json.load(open('$S/bench.json'))['build_id'])")
 export PROFILE_BUILD_ID=$BID
 cp $S/bench.json $D/${P}_bench.json
