@@ -383,17 +383,23 @@ __global__ __launch_bounds__(512) void pose_blend3_fwd_kernel(
 // workgroup per CU) when the grid is several rounds deep and the constant streams from L2 at its limit; two (190
 // registers, amdgpu_waves_per_eu 2: TWO workgroups per CU, one's first round trip and partial stores under the other's
 // loop) below 512 meshes - B = 128: 12.1 us against 13.1, B = 512: 47.7 / 47.7, B = 2 048: 200.8 against 182.5.
-template <int B3_DEPTH, int WPE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void blend3_bwd_kernel(const float *__restrict__ dvp,
-                                                         const u32x4 *__restrict__ pk, int B, int N3,
-                                                         int ktps, int nslices, int nmt,
-                                                         float *__restrict__ part) {
-  // XCD-aware map: the nmt mesh tiles of one column slice (same constant rows) share an XCD's L2.
+// From 512 meshes on a workgroup takes MT = 2 mesh tiles (three ahead, 324 + 128 registers): B = 512: 38.0 against 47.3,
+// 1 024: 67.6 against 91.7, 2 048: 132 against 181 us (four tiles: 216 - half the workgroups and a ring that spills).
+constexpr int B3_BIG_DEPTH = 3;   // k-tiles ahead in the two-tile form (ring of 4 x 40 registers + 128 accumulators)
+
+template <int B3_DEPTH, int WPE, int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void blend3_bwd_kernel(
+    const float *__restrict__ dvp, const u32x4 *__restrict__ pk, int B, int N3, int ktps, int nslices, int nmt,
+    float *__restrict__ part) {
+  // MT mesh tiles of 32 per workgroup (nmt counts the workgroups' tile GROUPS): every fragment of the constant a wave
+  // requests meets MT fragments of dv_posed - from 512 meshes on the kernel is bound by what L2 delivers of the
+  // constant (each XCD streams its slices' 3.4 MB once per tile group), and two tiles per group halve that.
+  // XCD-aware map: the nmt tile groups of one column slice (same constant rows) share an XCD's L2.
   const int bid = blockIdx.x;
   const int group = bid / (8 * nmt), within = bid % (8 * nmt);
   const int slice = group * 8 + (within & 7), mt = within >> 3;
   if (slice >= nslices) return;
-  const int m0 = mt * 32;
+  const int m0 = mt * 32 * MT;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 31, h = lane >> 5;
@@ -404,24 +410,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int kt_main = min(kt_end, nfull);                     // whole k-tiles; the matrix' ragged last tile comes after
   const int n = kt_main > kt_beg ? kt_main - kt_beg : 0;
 
-  f32x16 hi[2], lo[2];
+  f32x16 hi[MT][2], lo[MT][2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int j = 0; j < MT; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hi[t][r] = 0.0f; lo[t][r] = 0.0f; }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { hi[j][t][r] = 0.0f; lo[j][t][r] = 0.0f; }
 
-  const int mr = min(m0 + i, B - 1);                          // rows beyond B: clamped, never stored
-  const float *arow = dvp + (size_t)mr * N3 + 8 * h;
+  const float *arow[MT];
+  int mr[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    mr[j] = min(m0 + 32 * j + i, B - 1);                      // rows beyond B: clamped, never stored
+    arow[j] = dvp + (size_t)mr[j] * N3 + 8 * h;
+  }
   const u32x4 *b0 = pk + (size_t)u0 * 192 + lane, *b1 = pk + (size_t)u1 * 192 + lane;
 
-  f32x4u ra0[B3_DEPTH + 1], ra1[B3_DEPTH + 1];
+  f32x4u ra0[B3_DEPTH + 1][MT], ra1[B3_DEPTH + 1][MT];
   u32x4 rb[B3_DEPTH + 1][6];
   // (requests are unconditional with clamped tile indices: a branch around them would park the ring in scratch)
 #define SMPLR_LOAD_KT(slot, g)                                                    \
   {                                                                               \
     const int kt_ = min(kt_beg + (g), nfull - 1);                                 \
-    ra0[slot] = *reinterpret_cast<const f32x4u *>(arow + (size_t)kt_ * 16);       \
-    ra1[slot] = *reinterpret_cast<const f32x4u *>(arow + (size_t)kt_ * 16 + 4);   \
+    _Pragma("unroll") for (int j_ = 0; j_ < MT; ++j_) {                           \
+      ra0[slot][j_] = *reinterpret_cast<const f32x4u *>(arow[j_] + (size_t)kt_ * 16);     \
+      ra1[slot][j_] = *reinterpret_cast<const f32x4u *>(arow[j_] + (size_t)kt_ * 16 + 4); \
+    }                                                                             \
     _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                            \
       rb[slot][s_] = b0[((size_t)kt_ * 21 + s_) * 64];                            \
       rb[slot][3 + s_] = b1[((size_t)kt_ * 21 + s_) * 64];                        \
@@ -429,14 +444,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   }
 #define SMPLR_MMA_KT(slot)                                                         \
   {                                                                               \
-    const float x_[8] = {ra0[slot][0], ra0[slot][1], ra0[slot][2], ra0[slot][3],  \
-                         ra1[slot][0], ra1[slot][1], ra1[slot][2], ra1[slot][3]}; \
-    const Frag3 A = split8(x_);                                                   \
-    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                            \
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 0]);         \
-      const bf16x8 bm = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 1]);         \
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 2]);         \
-      SMPLR_MFMA_X3(A, bh, bm, bl, hi[t_], lo[t_])                                \
+    _Pragma("unroll") for (int j_ = 0; j_ < MT; ++j_) {                           \
+      const float x_[8] = {ra0[slot][j_][0], ra0[slot][j_][1], ra0[slot][j_][2], ra0[slot][j_][3],  \
+                           ra1[slot][j_][0], ra1[slot][j_][1], ra1[slot][j_][2], ra1[slot][j_][3]}; \
+      const Frag3 A = split8(x_);                                                 \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                          \
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 0]);       \
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 1]);       \
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, rb[slot][3 * t_ + 2]);       \
+        SMPLR_MFMA_X3(A, bh, bm, bl, hi[j_][t_], lo[j_][t_])                      \
+      }                                                                           \
     }                                                                             \
   }
 #pragma unroll
@@ -458,32 +475,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #undef SMPLR_MMA_KT
   if (kt_end > kt_main) {                      // block-uniform: the slice that owns the end of the matrix (N3 % 16 != 0)
     const int kt = nfull;
-    float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int cc = kt * 16 + 8 * h + j;      // columns >= N3 meet zeros in the packed constant
-      x[j] = dvp[(size_t)mr * N3 + min(cc, N3 - 1)];
-    }
-    const Frag3 A = split8(x);
+    for (int j = 0; j < MT; ++j) {
+      float x[8];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const u32x4 *bq = pk + ((size_t)kt * 21 + (t == 0 ? u0 : u1) * 3) * 64 + lane;
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[0]);
-      const bf16x8 bm = __builtin_bit_cast(bf16x8, bq[64]);
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[128]);
-      SMPLR_MFMA_X3(A, bh, bm, bl, hi[t], lo[t])
+      for (int q = 0; q < 8; ++q) {
+        const int cc = kt * 16 + 8 * h + q;    // columns >= N3 meet zeros in the packed constant
+        x[q] = dvp[(size_t)mr[j] * N3 + min(cc, N3 - 1)];
+      }
+      const Frag3 A = split8(x);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 *bq = pk + ((size_t)kt * 21 + (t == 0 ? u0 : u1) * 3) * 64 + lane;
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[0]);
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, bq[64]);
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, bq[128]);
+        SMPLR_MFMA_X3(A, bh, bm, bl, hi[j][t], lo[j][t])
+      }
     }
   }
-  // accumulator register r of lane (i, h) = mesh row (r&3) + 8(r>>2) + 4h, output 32u + i
-  float *dst = part + ((size_t)slice * nmt + mt) * (32 * B3_NO);
+  // accumulator register r of lane (i, h) = mesh row (r&3) + 8(r>>2) + 4h, output 32u + i; the partials keep their
+  // layout (slice, mesh tile of 32, 32, B3_NO) whatever MT
+  const int ntile = (B + 31) / 32;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (t == 1 && wave + 4 >= 7) break;        // wave-uniform
-    const int u = t == 0 ? u0 : u1;
+  for (int j = 0; j < MT; ++j) {
+    const int tile = mt * MT + j;
+    if (tile >= ntile) break;                  // block-uniform: the last group of an odd tile count
+    float *dst = part + ((size_t)slice * ntile + tile) * (32 * B3_NO);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      dst[row * B3_NO + 32 * u + i] = hi[t][r] + lo[t][r];
+    for (int t = 0; t < 2; ++t) {
+      if (t == 1 && wave + 4 >= 7) break;      // wave-uniform
+      const int u = t == 0 ? u0 : u1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        dst[row * B3_NO + 32 * u + i] = hi[j][t][r] + lo[j][t][r];
+      }
     }
   }
 }
@@ -494,7 +521,8 @@ Blend3BwdGeom blend3_bwd_geom(int B, int N3) {
   Blend3BwdGeom g;
   g.nmt = (B + 31) / 32;
   const int nkt = (N3 + 15) / 16;
-  int target = (256 + g.nmt - 1) / g.nmt;
+  const int ngrp = B >= 512 ? (g.nmt + 1) / 2 : g.nmt;     // workgroups per slice (two mesh tiles each from 512 meshes on)
+  int target = (256 + ngrp - 1) / ngrp;
   if (target < 8) target = 8;
   if (target > 60) target = 60;
   g.ktps = (nkt + target - 1) / target;
@@ -506,13 +534,16 @@ Blend3BwdGeom blend3_bwd_geom(int B, int N3) {
 int launch_blend3_bwd_partials(const float *dv_posed, const void *pk_bwd, int B, int N3, float *part,
                                hipStream_t st) {
   const Blend3BwdGeom g = blend3_bwd_geom(B, N3);
-  const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
-  if (B < 512)
-    hipLaunchKernelGGL((blend3_bwd_kernel<2, 2>), dim3(grid), dim3(256), 0, st, dv_posed,
+  if (B < 512) {
+    const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
+    hipLaunchKernelGGL((blend3_bwd_kernel<2, 2, 1>), dim3(grid), dim3(256), 0, st, dv_posed,
                        reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
-  else
-    hipLaunchKernelGGL((blend3_bwd_kernel<5, 1>), dim3(grid), dim3(256), 0, st, dv_posed,
-                       reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, g.nmt, part);
+  } else {
+    const int ngrp = (g.nmt + 1) / 2;          // two mesh tiles per workgroup
+    const int grid = ((g.nslices + 7) / 8) * 8 * ngrp;
+    hipLaunchKernelGGL((blend3_bwd_kernel<B3_BIG_DEPTH, 1, 2>), dim3(grid), dim3(256), 0, st, dv_posed,
+                       reinterpret_cast<const u32x4 *>(pk_bwd), B, N3, g.ktps, g.nslices, ngrp, part);
+  }
   SMPLR_LAUNCH_CHECK("blend3_bwd_kernel");
   return 0;
 }

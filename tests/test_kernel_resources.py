@@ -34,10 +34,10 @@ def test_raster_fwd_keeps_two_blocks_per_cu(kernels):
 
 @pytest.mark.parametrize("pat,threads,blocks", [
     ("seg_bin_kernel", 1024, 1), ("silh_px_kernel", 1024, 1), ("seg_bwd_kernel", 768, 1), ("skin_bwd_kernelILb1E", 256, 7),
-    ("pose_blend3_fwd_kernel", 512, 1), ("blend3_bwd_kernelILi5ELi1E", 256, 1), ("pose_bwd_kernel", 512, 1),
+    ("pose_blend3_fwd_kernel", 512, 1), ("blend3_bwd_kernelILi3ELi1ELi2E", 256, 1), ("pose_bwd_kernel", 512, 1),
     # the GEMMs' small-batch forms count on TWO workgroups per CU (one's first round trip under the other's loop, and
     # two mesh tiles of a column slice sharing the constant's lines in L1)
-    ("blend3_bwd_kernelILi2ELi2E", 256, 2), ("_ZN5smplr17blend3_fwd_kernel", 256, 2)])
+    ("blend3_bwd_kernelILi2ELi2ELi1E", 256, 2), ("_ZN5smplr17blend3_fwd_kernel", 256, 2)])
 def test_hot_path_kernels_fit_their_launch(kernels, pat, threads, blocks):
     """`blocks` workgroups of `threads` threads fit a CU's registers (4 SIMDs), without scratch."""
     for name, k in _match(kernels, pat).items():
