@@ -888,6 +888,11 @@ class DecoderOpts:
 # workgroup per CU where the plain GEMM fits two: B = 512: 52.4 against 7.2 + 42.1, B = 2 048: 191 against 9.2 + 136.4
 # (tools/probes/blend_big.py).  Bit-identical either way.
 POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "512"))
+# Batch below which the binning workgroups skin their own vertices (one launch less, no re-read of proj): with one
+# workgroup per mesh the skinning lengthens a latency chain that a half-empty chip does not feel - B = 128: -5 us,
+# B = 192: 0.1906 against 0.1937 ms per step - and that every CU pays once the chip is full: B = 256: 0.2222-0.225
+# against 0.2164-0.2181 for the separate skinning launch, 512: 0.425 / 0.403-0.411, 2 048: 1.508 / 1.480 (same box).
+FUSE_SKIN_BELOW_B = int(os.environ.get("SMPLR_FUSE_SKIN_BELOW_B", "256"))
 
 
 class DecoderFn(torch.autograd.Function):
@@ -968,7 +973,7 @@ class DecoderFn(torch.autograd.Function):
         # vertex is rasterised and the mesh fits the binning workgroup's LDS; SMPLR_FUSE_SKIN=0 keeps the two calls
         fuse_skin = (opts.seg and consts.lbs_top4 is not None and vs == 1
                      and bool(lib.smplr_skin_vis_seg_fits(V, W, int(grid_wh)))
-                     and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
+                     and B < FUSE_SKIN_BELOW_B and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
         sl = lambda t, lo, hi: None if t is None else t[lo:hi]
 
         def run(lo, hi):
