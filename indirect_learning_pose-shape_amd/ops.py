@@ -886,8 +886,9 @@ class DecoderOpts:
 # single launch (pose chain hidden under the GEMM, coefficient rows staged in 116 KB of LDS) wins while the grid is one
 # round of workgroups - B = 128: 17.3 us against 7.1 + 13.0 - and loses once it is many, because that LDS allows one
 # workgroup per CU where the plain GEMM fits two: B = 512: 52.4 against 7.2 + 42.1, B = 2 048: 191 against 9.2 + 136.4
-# (tools/probes/blend_big.py).  Bit-identical either way.
-POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "512"))
+# (tools/probes/blend_big.py); whole steps on one box: B = 256 0.2237 (one launch) against 0.230 ms, B = 384 0.349
+# against 0.3427.  Bit-identical either way.
+POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "320"))
 # Batch below which the binning workgroups skin their own vertices (one launch less, no re-read of proj): with one
 # workgroup per mesh the skinning lengthens a latency chain that a half-empty chip does not feel - B = 128: -5 us,
 # B = 192: 0.1906 against 0.1937 ms per step - and that every CU pays once the chip is full: B = 256: 0.2222-0.225
