@@ -103,6 +103,27 @@ def source_build_id():
     return h.hexdigest()
 
 
+def library_build_id(path=None):
+    """The id compiled into the library FILE at `path`, read in a child process: a ctypes.CDLL() in this process
+    would keep the file mapped, and glibc hands the same (old) mapping back for that path after a rebuild, so a
+    probe-then-rebuild-then-load sequence (tests/conftest.py) must not open it here.  None when the file is
+    missing, does not load, or has no smplr_build_id."""
+    import subprocess
+    import sys
+    path = LIB_PATH if path is None else path
+    if not os.path.exists(path):
+        return None
+    code = ("import ctypes,sys\n"
+            "f = ctypes.CDLL(sys.argv[1]).smplr_build_id\n"
+            "f.restype = ctypes.c_char_p\n"
+            "sys.stdout.write(f().decode('ascii'))\n")
+    try:
+        r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.SubprocessError):
+        return None
+    return r.stdout.strip() if r.returncode == 0 and r.stdout.strip() else None
+
+
 def build_id():
     """The id compiled into the loaded library."""
     return load().smplr_build_id().decode("ascii")

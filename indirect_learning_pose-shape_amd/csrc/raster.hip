@@ -544,9 +544,13 @@ __device__ __forceinline__ void lds_scan_tbl(const char *base, int beg, int end,
     tbl_keys<UNIT>(base, av, tv, fc2, a01, a23);
     tbl_keys<UNIT>(base, av + GP * 4, tv + GP * 4, fc2, b01, b23);
     const float na = fminf(fminf(a01.x, a01.y), fminf(fminf(a23.x, a23.y), best));
+#ifndef SMPLR_KO_TRACK
     bav = na < best ? av : bav;
+#endif
     const float nb = fminf(fminf(b01.x, b01.y), fminf(fminf(b23.x, b23.y), na));
+#ifndef SMPLR_KO_TRACK
     bav = nb < na ? tv : bav;
+#endif
     best = nb;
     av += 2 * GP * 4;
     tv += 2 * GP * 4;
@@ -577,7 +581,17 @@ __device__ __forceinline__ void scan_parts_tbl(const char *base, int offv, int p
     int bslot = -1;
     if (beg < end) {
       unsigned bav = (unsigned)beg * 4u;           // (no group lowers an infinite best: the first one is looked at)
+#ifdef SMPLR_KO_PAIRS
+      lds_scan_tbl<UNIT>(base, beg, beg + GP, rowoff, fc2, best, bav);
+#else
       lds_scan_tbl<UNIT>(base, beg, end, rowoff, fc2, best, bav);
+#endif
+#if defined(SMPLR_KO_RESCAN) || defined(SMPLR_KO_TRACK)
+      bslot = (int)(bav >> 2);
+    }
+    if (false) {
+      unsigned bav = 0;
+#endif
       // the winning group is looked at once more for the first record that attains the minimum
       const unsigned wav = tbl_group(bav, rowoff);
       f32x2 k01, k23;
@@ -587,7 +601,11 @@ __device__ __forceinline__ void scan_parts_tbl(const char *base, int offv, int p
       bslot = (best < INFINITY) ? w : -1;
     }
     // (no test for an empty part: sqrt(inf) = inf and v_exp_f32(-inf) = +0 exactly)
+#ifdef SMPLR_KO_FINAL
+    myS[p] = best;
+#else
     myS[p] = fast_exp_neg(fast_sqrt(best));
+#endif
     myA[p] = (short)bslot;
     beg = end;
   }
@@ -847,7 +865,11 @@ __global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel
       const int l1 = l1a[it];
       int i = l0a[it] + sub;
       uint2 rec = lr0[it];
+#ifdef SMPLR_KO_MERGE
+      while (false) {
+#else
       while (__any(i < l1)) {
+#endif
         const uint2 nxt = lrecn[min(i + 8, K - 1)];        // next step's record, in flight during this one
         if (i < l1) {
           const int sc = __float_as_int(fast_exp_neg(__uint_as_float(rec.x)));
@@ -949,6 +971,394 @@ __global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel
     // d loss / d score_c = (q_t softmax_t) (delta_ct - softmax_c)
     const float k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
     // what the background contributes to every channel's gradient where the clip's gate is open, per unit of k1
+    const float gbu = eg >= 0.0f ? ((t == 0 ? 1.0f : 0.0f) - eg * inv) : 0.0f;
+    if (sub < NIT && po != ~0u) {
+      lo.loss[(size_t)n * npix + po] = ls;
+      lo.stats[(size_t)n * npix + po] = make_float4(k1 * inv, k1 * gbu, k1, __int_as_float(t));
+    }
+  }
+  SMPLR_TL_STAMP(6);
+#ifdef SMPLR_TL
+  if (tl__) { tl__[7] = (unsigned)(pe0 - ps0); tl__[8] = (unsigned)g; }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// raster2_fwd_kernel: the same rasteriser with TWO pixels per lane (round 4).
+//
+// What the counters said about raster_fwd_kernel (profiles/raster_sq.json, tools/ab_kernel_b.sh knock-outs): of 99.6
+// vector instructions per (64-pixel wave, part) the pair arithmetic was under a third; with all but one record group
+// per part knocked out the kernel still took 23.6 of its 33.2 us.  The fixed cost per (wave, part) - part bookkeeping,
+// two dependent LDS round trips, the winner re-scan, address arithmetic - is what two pixels per lane attack:
+//  * a lane owns the pixels (2Q, c) and (2Q + 1, c): they share du = u - c, so a group of 4 records costs
+//    2 v_pk_add + 4 v_pk_fma + 4 v_min3 + 2 (cmp, cndmask) = 14 vector instructions for 8 pairs (was 9 for 4), three
+//    ds_read_b128 instead of four, and every per-part scalar / branch / setup instruction serves 128 pixels;
+//  * the block's table is laid out [group of 4 records][row][4]: row 0 = u, row 1 + j = (v - (row0 + j))^2, so a
+//    lane's two table rows are ADJACENT (one address register, immediate offsets 0 / 16) and the next group lies a
+//    compile-time R * 16 bytes on: four groups per trip through the loop with immediate offsets only, two address
+//    adds per 16 records instead of two per 8; the group id that is tracked is a scalar counter;
+//  * the table is built straight from the global records (thread = record: u and R - 1 squares) behind ONE barrier
+//    (was: copy, barrier, build, barrier);
+//  * the winner re-scan decodes nothing (the tracked id IS the group index).
+// Keys, tie rules, merge and write-out are raster_fwd_kernel's, expression for expression: outputs are bit-identical
+// (tools/probes/seg_hash.py).  Blocks whose tables do not fit (list longer than TREC(R), a weight other than 1, more
+// than 10 image rows under the block) walk the global record list with scalar loads - exact, slow, rare.
+constexpr int PLN = 128;                 // pair-lanes per block: 2 x 64
+constexpr int R2_MAX = 11;               // table rows + 1 of the largest instantiation
+__host__ __device__ constexpr int trec_of(int R) { return (ARENA / (4 * R)) * 4; }   // records the arena holds at R rows per group
+
+template <int R>
+__device__ __forceinline__ void scan2_body(const char *tb, unsigned vu, unsigned vt, int off, int gid, f32x2 fc2,
+                                           float &bestA, float &bestB, int &gA, int &gB) {
+  const f32x4 u = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(tb + vu + off, 16));
+  const f32x4 t0 = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(tb + vt + off, 16));
+  const f32x4 t1 = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(tb + vt + off + 16, 16));
+  const f32x2 du01 = u.xy - fc2, du23 = u.zw - fc2;
+  const f32x2 a01 = __builtin_elementwise_fma(du01, du01, t0.xy), a23 = __builtin_elementwise_fma(du23, du23, t0.zw);
+  const f32x2 b01 = __builtin_elementwise_fma(du01, du01, t1.xy), b23 = __builtin_elementwise_fma(du23, du23, t1.zw);
+  const float na = fminf(fminf(a01.x, a01.y), fminf(fminf(a23.x, a23.y), bestA));
+  const float nb = fminf(fminf(b01.x, b01.y), fminf(fminf(b23.x, b23.y), bestB));
+  // strict: the first group that attains the minimum keeps it.  (Written as "not less ? old : new" so that the
+  // scalar group counter can be the select's SGPR operand - v_cndmask takes one only as its "false" value.)
+  gA = !(na < bestA) ? gA : gid;
+  gB = !(nb < bestB) ? gB : gid;
+  bestA = na;
+  bestB = nb;
+}
+
+// first record of group g (table row ra) whose key equals best -> its slot
+template <int R>
+__device__ __forceinline__ int rescan2(const char *tb, int g, unsigned va, f32x2 fc2, float best) {
+  const unsigned wa = __umul24((unsigned)g, (unsigned)(R * 16));   // (v_mul_u32_u24: full rate; g < 2^24)
+  const f32x4 u = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(tb + wa, 16));
+  const f32x4 t = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(tb + wa + va, 16));
+  const f32x2 du01 = u.xy - fc2, du23 = u.zw - fc2;
+  const f32x2 k01 = __builtin_elementwise_fma(du01, du01, t.xy), k23 = __builtin_elementwise_fma(du23, du23, t.zw);
+  const int w23 = (k23.x == best) ? 2 : 3, w13 = (k01.y == best) ? 1 : w23;
+  const int w = g * 4 + ((k01.x == best) ? 0 : w13);
+  return (best < INFINITY) ? w : -1;
+}
+
+// A wave's parts [ps, pe) for its 64 pair-lanes, unit weights, table mode.  offv: the part offsets, one per lane.
+template <int R>
+__device__ __forceinline__ void scan2_parts(const char *tb, int offv, int ps, int pe, unsigned va, f32x2 fc2,
+                                            float *myS, short *myA) {
+  constexpr int GB = R * 16;             // bytes per group
+  int beg = __builtin_amdgcn_readlane(offv, ps);
+  for (int p = ps; p < pe; ++p) {
+    const int end = __builtin_amdgcn_readlane(offv, p + 1);
+    float bestA = INFINITY, bestB = INFINITY;
+    int sA_ = -1, sB_ = -1;
+    if (beg < end) {
+      int gid = beg >> 2;
+      const int ngrp = (end - beg) >> 2;
+      int gA = gid, gB = gid;
+      unsigned vu = (unsigned)gid * GB, vt = vu + va;
+      asm volatile("" : "+v"(vu));
+      asm volatile("" : "+v"(vt));
+      int g = 0;
+      for (; g + 4 <= ngrp; g += 4) {
+        scan2_body<R>(tb, vu, vt, 0, gid, fc2, bestA, bestB, gA, gB);
+        scan2_body<R>(tb, vu, vt, GB, gid + 1, fc2, bestA, bestB, gA, gB);
+        scan2_body<R>(tb, vu, vt, 2 * GB, gid + 2, fc2, bestA, bestB, gA, gB);
+        scan2_body<R>(tb, vu, vt, 3 * GB, gid + 3, fc2, bestA, bestB, gA, gB);
+        vu += 4 * GB;
+        vt += 4 * GB;
+        gid += 4;
+      }
+      if ((ngrp - g) & 2) {
+        scan2_body<R>(tb, vu, vt, 0, gid, fc2, bestA, bestB, gA, gB);
+        scan2_body<R>(tb, vu, vt, GB, gid + 1, fc2, bestA, bestB, gA, gB);
+        vu += 2 * GB;
+        vt += 2 * GB;
+        gid += 2;
+      }
+      if ((ngrp - g) & 1) scan2_body<R>(tb, vu, vt, 0, gid, fc2, bestA, bestB, gA, gB);
+      sA_ = rescan2<R>(tb, gA, va, fc2, bestA);
+      sB_ = rescan2<R>(tb, gB, va + 16, fc2, bestB);
+    }
+    // (no test for an empty part: sqrt(inf) = inf and v_exp_f32(-inf) = +0 exactly)
+    myS[p] = fast_exp_neg(fast_sqrt(bestA));
+    myS[SLD + p] = fast_exp_neg(fast_sqrt(bestB));
+    myA[p] = (short)sA_;
+    myA[ALD + p] = (short)sB_;
+    beg = end;
+  }
+}
+
+template <bool LOSS, int NG2>
+__global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS void raster2_fwd_kernel(
+    const float4 *__restrict__ G, const int *__restrict__ goff, const int *__restrict__ lstart,
+    const uint2 *__restrict__ lrec, int P, int K, int S, int W, int B, int ntiles, float *__restrict__ seg,
+    short *__restrict__ arg, unsigned wmagic, LossOut lo, int stagger_blocks, int stagger_cycles) {
+  constexpr int NT = PLN * NG2;          // threads
+  __shared__ float sS[RTS * SLD];
+  __shared__ short sA[RTS * ALD];
+  __shared__ f32x4 sTab[ARENA / 4];      // [group][row 0 = u | rows 1.. = (v - row)^2][4 records]
+  __shared__ int sOff[40];
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int n = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
+  if (n >= B) return;                                    // block-uniform
+  const int tid = threadIdx.x, lane = tid & 63;
+  SMPLR_TL_WAVE(g_tl_raster, 16, n * ntiles + tile, TL_RASTER_WG)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 1, pw = wave & 1;                // part range, 64-lane half of the block
+  const int npix = W * W;
+  const int nq = (W + 1) >> 1, nl = nq * W;              // row pairs, pair-lanes of an image
+  // this lane's pixel pair: pair-lane L = Q W + c -> pixels (2Q, c), (2Q + 1, c)
+  const int Lb = pw * 64 + lane;
+  const int L = min(tile * PLN + Lb, nl - 1);
+  const int Q = (int)(((unsigned)L * wmagic) >> 24), c = L - Q * W;     // L < W^2 <= 25600: exact (see raster_fwd_kernel)
+  // rows under the block: pairs Qf .. Ql
+  const int Qf = (int)(((unsigned)min(tile * PLN, nl - 1) * wmagic) >> 24);
+  const int Ql = (int)(((unsigned)min(tile * PLN + PLN - 1, nl - 1) * wmagic) >> 24);
+  const int row0 = 2 * Qf, nrows = 2 * (Ql - Qf + 1);    // (an odd W's last pair has a phantom row W: built, never written out)
+  const float4 *Gn = G + (size_t)n * S;
+  const int *goffn = goff + (size_t)n * (P + 2);
+  const int C = P + 1;
+  // merge / write-out items: item e = it * NT + tid is tile pixel e / 8 (= 2 x pair-lane + row of the pair), channels 4 (e % 8) ..
+  constexpr int NIT = RTS * 8 / NT;
+  const int sub = tid & 7;
+  int l0a[NIT], l1a[NIT], qqa[NIT];
+  int lab[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int pl = (it * NT + tid) >> 3;
+    const int Li = tile * PLN + (pl >> 1);
+    const int Lc = min(Li, nl - 1);
+    const int Qi = (int)(((unsigned)Lc * wmagic) >> 24), ci = Lc - Qi * W;
+    const int ri = 2 * Qi + (pl & 1);
+    const bool ok = Li < nl && ri < W;
+    const int qq = ok ? ri * W + ci : -1;                // the item's pixel (row-major, unflipped), -1: none
+    qqa[it] = qq;
+    const int *lp = lstart + (size_t)n * (npix + 1) + (ok ? qq : 0);
+    l0a[it] = lp[0];
+    l1a[it] = ok ? lp[1] : 0;                            // pixels past the image merge nothing
+    lab[it] = 0;
+    if (LOSS) {                                          // labels lie as the output does: rows flipped
+      const int rr = ok ? ri : 0;
+      lab[it] = lo.labels[(size_t)n * npix + (unsigned)((W - 1 - rr) * W + ci)];
+    }
+  }
+  const uint2 *lrecn = lrec + (size_t)n * K;
+  const int lbase = goffn[P];
+  const bool unit_m = goffn[P + 1] == 0;                 // every far-reaching weight is 1 (block-uniform)
+  if (tid <= P) sOff[tid] = goffn[tid];
+  // table rows per group at this block: the smallest instantiation that holds its image rows
+  const int Rb = nrows <= 4 ? 5 : nrows <= 6 ? 7 : nrows <= 8 ? 9 : 11;
+  const int trec = (ARENA / (4 * Rb)) * 4;
+  // thread i asks for record i (and i + NT ... while the arena could hold it) before the list length is known: the
+  // records share the block's first round trip to memory; slots beyond the list hold stale bytes nobody reads
+  constexpr int NH = (trec_of(5) + NT - 1) / NT;
+  float4 rcs[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+    rcs[h] = (h == 0 || tid + h * NT < trec) ? Gn[min(tid + h * NT, S - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool tbl = unit_m && nrows <= R2_MAX - 1 && lbase <= trec;     // block-uniform
+  // Stagger (speed only, no effect on results): two blocks share a CU, start together and - all blocks costing the
+  // same - stay in step for the whole launch: both in their vector-bound scan, then both in their latency-bound
+  // prologue / barrier / write-out, the vector unit idle.  The second block of a CU's first pair (it sits in wave
+  // slots 4-7 of each SIMD, HW_ID[3:0]: tools/probes/raster_slots.py) waits here, behind its requests, for about half
+  // a block's lifetime; every later block starts when a slot frees, i.e. already out of step with its neighbour.
+  if (bid < stagger_blocks) {
+    if ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u) >= 4u) {      // HW_REG_HW_ID, bits 3:0 = wave slot
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger_cycles) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  SMPLR_TL_STAMP(1);
+  if (tbl) {
+    float *tab = reinterpret_cast<float *>(sTab);
+    const float fr0 = (float)row0;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int i = tid + h * NT;
+      const float4 rcd = rcs[h];
+      if (i < lbase) {
+        float *dst = tab + ((i >> 2) * Rb) * 4 + (i & 3);
+        dst[0] = rcd.x;
+#pragma unroll
+        for (int j = 0; j < R2_MAX - 1; ++j) {
+          if (j < Rb - 1) {                              // (Rb is block-uniform)
+            const float dv = rcd.y - (fr0 + (float)j);
+            dst[(1 + j) * 4] = dv * dv;
+          }
+        }
+      }
+    }
+  }
+  SMPLR_TL_STAMP(2);
+  __syncthreads();
+  SMPLR_TL_STAMP(3);
+  // the first 8 local records of each of this lane's merge pixels are fetched now and used after the pair loop
+  uint2 lr0[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) lr0[it] = lrecn[min(l0a[it] + sub, K - 1)];
+  float wlab[NIT];                                       // LOSS: the labelled class' weight (focal_loss.py:20-41)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    wlab[it] = (LOSS && lo.class_w) ? lo.class_w[min(max(lab[it], 0), 31)] : 1.0f;
+  const float fc = (float)c;
+  const f32x2 fc2 = {fc, fc};
+  float *myS = &sS[(2 * Lb) * SLD + 1];                  // indexed by part (channel = part + 1); second pixel at + SLD
+  short *myA = &sA[(2 * Lb) * ALD + 1];
+
+  // this wave's parts [ps, pe): as raster_fwd_kernel cuts them (midpoint of the part's span in the cost prefix)
+  int ps, pe;
+  {
+    const int lp = lane < P ? lane : 0;                  // P <= 31 parts
+    const int mid2 = sOff[lp] + sOff[lp + 1] + PART_COST * (2 * lp + 1);     // 2 x midpoint
+    const int total = __builtin_amdgcn_readfirstlane(sOff[P]) + PART_COST * P;
+    const unsigned long long b0 = __ballot(lane < P && NG2 / 2 * mid2 < total * g);          // mid2 / 2 < total g / NG2
+    const unsigned long long b1 = __ballot(lane < P && NG2 / 2 * mid2 < total * (g + 1));
+    ps = (g == 0) ? 0 : __popcll(b0);
+    pe = (g == NG2 - 1) ? P : __popcll(b1);
+  }
+#ifdef SMPLR_TL
+  const int ps0 = ps, pe0 = pe;
+#endif
+  {
+    const int offv = sOff[lane <= P ? lane : P];
+    const char *tb = reinterpret_cast<const char *>(sTab);
+    const unsigned va = (unsigned)(1 + 2 * (Q - Qf)) * 16u;      // byte offset of the upper pixel's table row in a group
+    if (tbl) {
+      if (Rb == 5) scan2_parts<5>(tb, offv, ps, pe, va, fc2, myS, myA);
+      else if (Rb == 7) scan2_parts<7>(tb, offv, ps, pe, va, fc2, myS, myA);
+      else if (Rb == 9) scan2_parts<9>(tb, offv, ps, pe, va, fc2, myS, myA);
+      else scan2_parts<11>(tb, offv, ps, pe, va, fc2, myS, myA);
+    } else {
+      // the global record list by scalar loads, one record at a time (strict '<': the first arg-min in list order)
+      const float fr0 = (float)(2 * Q), fr1 = fr0 + 1.0f;
+      int beg = __builtin_amdgcn_readlane(offv, ps);
+      for (int p = ps; p < pe; ++p) {
+        const int end = __builtin_amdgcn_readlane(offv, p + 1);
+        float bestA = INFINITY, bestB = INFINITY;
+        int sA_ = -1, sB_ = -1;
+        for (int k = beg; k < end; ++k) {
+          const float4 rcd = Gn[k];
+          const float ka = pair_key(rcd, fc, fr0), kb = pair_key(rcd, fc, fr1);
+          const bool la = ka < bestA, lb = kb < bestB;
+          bestA = la ? ka : bestA;
+          sA_ = la ? k : sA_;
+          bestB = lb ? kb : bestB;
+          sB_ = lb ? k : sB_;
+        }
+        myS[p] = (bestA < INFINITY) ? fast_exp_neg(fast_sqrt(bestA)) : 0.0f;
+        myS[SLD + p] = (bestB < INFINITY) ? fast_exp_neg(fast_sqrt(bestB)) : 0.0f;
+        myA[p] = (short)sA_;
+        myA[ALD + p] = (short)sB_;
+        beg = end;
+      }
+    }
+  }
+  SMPLR_TL_STAMP(4);
+  __syncthreads();
+  SMPLR_TL_STAMP(5);
+  // merge of the local records and write-out: raster_fwd_kernel's, item for item (see there)
+  float den_[NIT], st_[NIT], eg_[NIT];
+  unsigned po_[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = it * NT + tid;
+    const int pl = e >> 3, c4 = (e & 7) * 4;
+    {
+      int *rowS = reinterpret_cast<int *>(&sS[pl * SLD + 1]);
+      short *rowA = &sA[pl * ALD + 1];
+      const int l1 = l1a[it];
+      int i = l0a[it] + sub;
+      uint2 rec = lr0[it];
+      while (__any(i < l1)) {
+        const uint2 nxt = lrecn[min(i + 8, K - 1)];        // next step's record, in flight during this one
+        if (i < l1) {
+          const int sc = __float_as_int(fast_exp_neg(__uint_as_float(rec.x)));
+          const int p = (int)rec.y;
+          const int old = atomicMax(&rowS[p], sc);
+          const int fin = __hip_atomic_load(&rowS[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);   // (a ds_read, not a flat load)
+          if (old < sc && fin == sc) rowA[p] = (short)(lbase + i);
+        }
+        rec = nxt;
+        i += 8;
+      }
+    }
+    const float *ts = &sS[pl * SLD + c4];
+    const short *ta = &sA[pl * ALD + c4];
+    float v[4];
+    short a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[t] = ts[t];
+      a[t] = ta[t];
+    }
+    if (c4 == 0) v[0] = 0.0f;                              // the tile holds nothing for channel 0 ...
+    if (C != 32) {                                         // ... nor for slots >= C (block-uniform: not the reference's 31 parts)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c4 + t >= C) {
+          v[t] = 0.0f;
+          a[t] = (short)-1;
+        }
+      }
+    }
+    const float sum = sum8_dpp((v[0] + v[1]) + (v[2] + v[3]));   // over the pixel's parts (all lanes take part)
+    float vmx = 0.0f;
+    if (lo.vmax) vmx = max8_dpp(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));   // (block-uniform; channel 0 holds 0 here)
+    if (c4 == 0) {
+      v[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
+      a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
+    }
+    const int qq = qqa[it];
+    if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
+      den_[it] = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
+      const int t = lab[it];
+      const float vt = (t & 2) ? ((t & 1) ? v[3] : v[2]) : ((t & 1) ? v[1] : v[0]);
+      st_[it] = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);      // the labelled class' score in all 8 lanes (+ exact zeros)
+      const float eg = a[0] ? __expf(v[0]) : -1.0f;
+      eg_[it] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(eg), 0x00, 0xF, 0xF, false));
+    }
+    unsigned po = ~0u;
+    if (qq >= 0) {
+      const int rr = (int)(((unsigned)qq * wmagic) >> 24), cc = qq - rr * W;
+      po = (unsigned)((W - 1 - rr) * W + cc);              // rows flipped (:68); mesh base + 32-bit offset
+    }
+    if (LOSS) po_[it] = po;
+    if (qq >= 0 && c4 < C) {
+      if (lo.vmax && c4 == 0) lo.vmax[(size_t)n * npix + po] = vmx;
+      float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
+      if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
+      } else if (c4 + 3 < C && (C & 3) == 0) {
+        SMPLR_OUT_STORE(reinterpret_cast<f32x4 *>(so), (f32x4{v[0], v[1], v[2], v[3]}));
+      } else {
+        for (int t = 0; t < 4; ++t)
+          if (c4 + t < C) so[t] = v[t];
+      }
+      short4 o4;
+      o4.x = a[0]; o4.y = a[1]; o4.z = a[2]; o4.w = a[3];
+      *reinterpret_cast<short4 *>(arg + (size_t)n * npix * 32 + (po * 32u + (unsigned)c4)) = o4;
+    }
+  }
+  if (LOSS) {
+    // the per-pixel end of the loss once for all merge steps of the lane: lane `it` of a pixel's 8 finishes step `it`
+    static_assert(!LOSS || NIT <= 4, "the background's lane reaches its quad only");
+    float den = den_[0], st = st_[0], eg = eg_[0], w = wlab[0];
+    int t = lab[0];
+    unsigned po = po_[0];
+#pragma unroll
+    for (int it = 1; it < NIT; ++it) {
+      if (sub == it) {
+        den = den_[it]; st = st_[it]; eg = eg_[it]; w = wlab[it];
+        t = lab[it];
+        po = po_[it];
+      }
+    }
+    const float inv = __builtin_amdgcn_rcpf(den);
+    const float sm = __expf(st) * inv;
+    const float p = fminf(fmaxf(sm, K_EPS), 1.0f - K_EPS);                     // focal_loss.py:17
+    const bool inside = sm >= K_EPS && sm <= 1.0f - K_EPS && (unsigned)t < 32u;  // (a label outside the classes: no loss)
+    const float om = 1.0f - p, lg = __builtin_amdgcn_logf(p) * 0.6931471806f;
+    const float pg = pow_gamma(om, lo.gamma);
+    const float ls = (unsigned)t < 32u ? pg * ((-lg) * w) : 0.0f;              // :18, :41, :43-44
+    const float k1 = inside ? (w * (dpow_gamma(om, lo.gamma) * lg - pg * __builtin_amdgcn_rcpf(p))) * sm : 0.0f;
     const float gbu = eg >= 0.0f ? ((t == 0 ? 1.0f : 0.0f) - eg * inv) : 0.0f;
     if (sub < NIT && po != ~0u) {
       lo.loss[(size_t)n * npix + po] = ls;
@@ -1852,7 +2262,9 @@ __global__ __launch_bounds__(SF_T) void silh_px_kernel(const float *__restrict__
         lim = d2 * 1.000001f;
         rows = 7ull << (cy - 1);                            // rows cy - 1 .. cy + 1 (cy >= SM)
       }
-    } else if (hs > 0.0f) {
+    } else if (hs > 1e-30f && hs <= 1.0f) {
+      // (a hint outside (1e-30, 1] - a denormal, a NaN, garbage handed to smplr_silh_fwd_hint - is no hint: -log of it
+      // would make the row window overflow and the pixel would come back empty instead of exact; step (2) searches)
       // (2') some vertex lies within -log(hs) of the pixel (+ 1e-3 for the approximate exp / log): every row in reach
       const float b = 1e-3f - __logf(hs);
       lim = b * b * 1.0001f;
@@ -2175,6 +2587,57 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
   const char *base = reinterpret_cast<const char *>(workspace);
+  // SMPLR_RASTER=1: the one-pixel-per-lane kernel of rounds 1-3 (kept for A/B runs); SMPLR_RASTER_NG: part ranges per
+  // pixel of the two-pixel kernel (4: 512-thread blocks, 8: 1 024)
+  static const int version = getenv("SMPLR_RASTER") ? atoi(getenv("SMPLR_RASTER")) : 2;
+  static const int ng2 = getenv("SMPLR_RASTER_NG") ? atoi(getenv("SMPLR_RASTER_NG")) : 8;
+  if (version != 1) {
+    const int nl = ((W + 1) / 2) * W, nt2 = (nl + PLN - 1) / PLN;
+    const int grid2 = 8 * ((B + 7) / 8) * nt2;
+    const unsigned wm = (unsigned)(((1u << 24) + W - 1) / W);
+    const float4 *Gp = reinterpret_cast<const float4 *>(rec);
+    const int *goffp = reinterpret_cast<const int *>(base + ws.goff_off);
+    const int *lsp = reinterpret_cast<const int *>(base + ws.lstart_off);
+    const uint2 *lrp = reinterpret_cast<const uint2 *>(base + ws.lrec_off);
+    short *argp = reinterpret_cast<short *>(arg);
+    // stagger: the first 2 x CUs blocks are the launch's first round (two 16-wave blocks per CU); off for grids that
+    // do not fill it
+    static const int stag_env = getenv("SMPLR_RASTER_STAGGER") ? atoi(getenv("SMPLR_RASTER_STAGGER")) : 0;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      hipDeviceProp_t pr;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
+      else n_cu = 256;
+    }
+    const int stag_cyc = stag_env;
+    const int stag_blocks = (stag_cyc > 0 && grid2 >= 2 * n_cu) ? 2 * n_cu : 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (kernel_ms) {
+      SMPLR_HIP(hipEventCreate(&e0));
+      SMPLR_HIP(hipEventCreate(&e1));
+    }
+#define SMPLR_RASTER2_LAUNCH(LOSS_, NG_)                                                                            \
+  {                                                                                                                 \
+    if (kernel_ms)                                                                                                  \
+      hipExtLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_>), dim3(grid2), dim3(PLN * NG_), 0, as_stream(stream), e0, \
+                            e1, 0, Gp, goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo, stag_blocks, stag_cyc); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_>), dim3(grid2), dim3(PLN * NG_), 0, as_stream(stream), Gp,  \
+                         goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo, stag_blocks, stag_cyc);            \
+  }
+    if (with_loss) { if (ng2 == 4) SMPLR_RASTER2_LAUNCH(true, 4) else SMPLR_RASTER2_LAUNCH(true, 8) }
+    else { if (ng2 == 4) SMPLR_RASTER2_LAUNCH(false, 4) else SMPLR_RASTER2_LAUNCH(false, 8) }
+#undef SMPLR_RASTER2_LAUNCH
+    SMPLR_LAUNCH_CHECK(fn);
+    if (kernel_ms) {
+      SMPLR_HIP(hipEventSynchronize(e1));
+      SMPLR_HIP(hipEventElapsedTime(kernel_ms, e0, e1));
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+    return 0;
+  }
   const int ntiles = (W * W + RTS - 1) / RTS;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
 #define SMPLR_RASTER_LAUNCH(LOSS_)                                                                             \

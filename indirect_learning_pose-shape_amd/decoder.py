@@ -49,6 +49,8 @@ class SMPLDecoder(nn.Module):
             raise ValueError("outputs must be a subset of ('verts', 'projects', 'mask'), got %r" % (outputs,))
         self.outputs = outputs
         self.num_cam, self.grid_wh, self.ref_compat = int(num_cam), int(grid_wh), bool(ref_compat)
+        if "seg" in heads and not 0 < self.grid_wh <= 128:   # compute_mask.py:44 hard-codes 64; the z-buffer holds 128 x 128
+            raise ValueError("grid_wh must be in 1..128, got %r" % (grid_wh,))
         self.with_silhouette = bool(with_silhouette)
         # the silhouette may have its own resolution (train_stage2_silhouette.py:72-86: `silhs_output_wh`)
         self.silh_wh = int(silh_wh) if silh_wh is not None else self.img_wh

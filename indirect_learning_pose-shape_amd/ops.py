@@ -896,6 +896,9 @@ POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "320"))
 FUSE_SKIN_BELOW_B = int(os.environ.get("SMPLR_FUSE_SKIN_BELOW_B", "256"))
 
 
+SILH_HINT_MAX_W = 48     # smplr_silh_fwd_hint uses the hint in silh_px_kernel only (W <= 48, raster.hip)
+
+
 class DecoderFn(torch.autograd.Function):
     """The model.py:108-118 chain as ONE autograd node.
 
@@ -927,6 +930,10 @@ class DecoderFn(torch.autograd.Function):
         Ws = 0 if not with_silh else (W if with_silh is True else int(with_silh))
         if not opts.seg and not with_silh:
             raise RuntimeError("DecoderFn: no head asked for (opts.seg = False needs a silhouette)")
+        # (smplr_seg_bin reads grid_wh <= 0 as "the mask is an INPUT": the decoder always computes it, so a bad value
+        # would rasterise from an uninitialised mask on the two-call path - refuse it here for every path)
+        if opts.seg and not 0 < int(grid_wh) <= 128:
+            raise RuntimeError("DecoderFn: grid_wh must be in 1..128 (got %r)" % (grid_wh,))
         V, VP = consts.V, (consts.V + vs - 1) // vs
         dev = x.device
         none = lambda: torch.empty(0, device=dev)
@@ -967,7 +974,9 @@ class DecoderFn(torch.autograd.Function):
             silh = sarg = None
         # both heads at one resolution: the part rasteriser hands the silhouette rasteriser each pixel's largest part
         # score - an upper bound of the distance to the nearest vertex that spares it its own search for one
-        vmax = _empty((B, W, W), x) if (with_silh and opts.seg and Ws == W and pt.P == 31
+        # (only where the silhouette rasteriser reads it: its pixel-per-lane kernel, W <= SILH_HINT_MAX_W - beyond that
+        # the step would pay for a (B,W,W) store and the slower `_ex` launch shape for a hint nobody uses)
+        vmax = _empty((B, W, W), x) if (with_silh and opts.seg and Ws == W and W <= SILH_HINT_MAX_W and pt.P == 31
                                         and os.environ.get("SMPLR_SILH_HINT", "1") != "0") else None
 
         # the binning workgroups skin their own vertices (one launch less) when the skinning rows are sparse, every

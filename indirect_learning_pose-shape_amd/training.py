@@ -38,6 +38,12 @@ class SegTrainer:
         self.decoder = SMPLDecoder(smpl_path, img_wh=output_wh, with_silhouette=with_silhouette, silh_wh=silh_wh,
                                    outputs=(), loss=self.loss_fn if fused_loss else None)
         self.with_silhouette = with_silhouette
+        # what the reference's monitor step reads every 10 trials (train.py:245-300: `verts_model` / `projects_model` /
+        # `segs_model` predictions of the monitor images): verts, projects, mask and the raw scores - the train
+        # decoder above writes none of them.  Same constants, no second upload; `on_trial_end(trial, trainer)` hooks
+        # use `trainer.monitor(images)`.
+        self.monitor_decoder = SMPLDecoder(smpl_path, img_wh=output_wh, with_silhouette=with_silhouette,
+                                           silh_wh=silh_wh).share_constants(self.decoder)
         # the silhouette-only pass of the reference's alternating schedule (train_stage2_silhouette.py:262-270)
         self.silh_decoder = (SMPLDecoder(smpl_path, img_wh=output_wh, heads=("silhouette",), silh_wh=silh_wh, outputs=())
                              .share_constants(self.decoder)) if with_silhouette else None
@@ -74,6 +80,21 @@ class SegTrainer:
         loss.backward()
         self.opt.step()
         return loss.detach()
+
+    @torch.no_grad()
+    def monitor(self, images):
+        """The monitor step's predictions (train.py:245-262) for a batch of images: dict(smpl (N,86), verts, projects,
+        mask, seg (N,W,W,32) raw scores [, silhouette], J_transformed) from the full-output decoder.  `step()`'s own
+        decoder returns losses only (outputs=()), so monitor hooks must not read `trainer.decoder(...)['verts']`."""
+        was_training = self.smpl_model.training
+        self.smpl_model.eval()
+        try:
+            param = self.smpl_model(images)
+            out = dict(self.monitor_decoder(param))
+        finally:
+            self.smpl_model.train(was_training)
+        out["smpl"] = param
+        return out
 
     def state_dict(self):                                           # train.py:302-315 saves smpl_model only
         return self.smpl_model.state_dict()
@@ -118,7 +139,8 @@ def fit(trainer, batches, trials, steps_per_trial, save_dir=None, save_every=10,
     """The loop of train.py:221-315: `trials` rounds of `steps_per_trial` optimiser steps (`fit_generator(...,
     steps_per_epoch, nb_epoch=1)`) over `batches` - an iterator of (images, labels[, silhouette labels]) already
     on the device, the data generators being the caller's - and every `save_every` trials (on rank 0) the monitor
-    hook and a checkpoint named like the reference's.  -> list of per-trial mean losses (python floats; the one
+    hook `on_trial_end(trial, trainer)` (use `trainer.monitor(images)` for verts / projects / seg: the train decoder
+    `trainer.decoder` writes losses only) and a checkpoint named like the reference's.  -> list of per-trial mean losses (python floats; the one
     host sync per trial)."""
     it = iter(batches)
     rank0 = (not dist.is_initialized()) or dist.get_rank() == 0

@@ -19,24 +19,15 @@ def _ensure_built():
     """The shared library is git-ignored: (re)build it in-tree when it is missing or was NOT built from the
     sources beside it - decided by the build id compiled into it (sha256 of csrc/*.hip, csrc/*.h and the header),
     not by file times, which a copy to another box can equalise (hipcc cross-compiles gfx950 without a GPU).
+    The id is read by `_lib.library_build_id()` in a child process, so this process never maps the stale file.
     Building the product is not a fallback: every op still fails loudly if the library cannot be loaded, and
     `_lib.load()` itself refuses a library whose id differs from its sources."""
-    import ctypes
     import subprocess
     from ilps_amd import _lib
     csrc = os.path.join(ROOT, "indirect_learning_pose-shape_amd", "csrc")
 
-    def built_id():
-        if not os.path.exists(_lib.LIB_PATH):
-            return None
-        try:
-            fn = ctypes.CDLL(_lib.LIB_PATH).smplr_build_id
-        except (OSError, AttributeError):
-            return None
-        fn.restype = ctypes.c_char_p
-        return fn().decode("ascii")
-
-    if built_id() != _lib.source_build_id():
+    # (read in a child process: a CDLL() here would pin the stale mapping and the load after the rebuild would get it back)
+    if _lib.library_build_id() != _lib.source_build_id():
         subprocess.run(["make", "-C", csrc, "-B", "-j4"], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.STDOUT)
 

@@ -100,3 +100,32 @@ def test_library_is_built_from_the_sources_beside_it(monkeypatch):
     monkeypatch.setattr(_lib, "source_build_id", lambda: "0" * 64)
     with pytest.raises(RuntimeError, match="built from other sources"):
         _lib.load()
+
+
+def test_probing_a_stale_library_does_not_pin_its_mapping(tmp_path):
+    """tests/conftest.py reads the built id, rebuilds when it is stale, then `_lib.load()` opens the file: the probe
+    must not leave the old file mapped in this process (glibc would hand the same handle back for that path and the
+    rebuilt library would never be seen).  Reproduced with a toy library built twice under one path."""
+    import shutil
+    import subprocess
+    from ilps_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    so = str(tmp_path / "libtoy.so")
+
+    def build(tag):
+        src = tmp_path / ("toy_%s.c" % tag[:4])
+        src.write_text('const char *smplr_build_id(void) { return "%s"; }\n' % tag)
+        subprocess.run(["gcc", "-shared", "-fPIC", "-o", so + ".new", str(src)], check=True)
+        os.replace(so + ".new", so)
+
+    old, new = "a" * 64, "b" * 64
+    build(old)
+    assert _lib.library_build_id(so) == old           # the probe conftest makes (child process)
+    build(new)                                        # "make -B"
+    fn = ctypes.CDLL(so).smplr_build_id               # what _lib.load() does afterwards, in this process
+    fn.restype = ctypes.c_char_p
+    assert fn().decode("ascii") == new
+    assert _lib.library_build_id(str(tmp_path / "missing.so")) is None
+    (tmp_path / "junk.so").write_bytes(b"not an ELF file")
+    assert _lib.library_build_id(str(tmp_path / "junk.so")) is None

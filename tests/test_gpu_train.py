@@ -256,10 +256,20 @@ def test_fit_loop_saves_and_resumes(smpl_model, tmp_path):
     labels = torch.randint(0, 32, (B, 48, 48), device=dev)
     name = lambda t_: save_name("up-s31", 48, True, 0.005, None, True, t_, encoder="enet")
     assert name(10) == "up-s31_48x48_enet_ief_scaledown0005_arms_weighted_2_bg_weighted_0point3_gamma2_multigpu_10.pt"
-    seen = []
+    seen, shapes = [], []
+
+    def monitor_hook(t_, trainer):                        # train.py:245-262's monitor step through the trainer
+        seen.append(t_)
+        out = trainer.monitor(images)
+        shapes.append({k: tuple(v.shape) for k, v in out.items()})
+        assert trainer.smpl_model.training                # the hook leaves the regressor in train mode
+
     hist = fit(tr, itertools.repeat((images, labels)), trials=3, steps_per_trial=2, save_dir=str(tmp_path), save_every=2,
-               name_fn=name, on_trial_end=lambda t_, _tr: seen.append(t_))
+               name_fn=name, on_trial_end=monitor_hook)
     assert len(hist) == 3 and all(np.isfinite(hist)) and seen == [0, 2]
+    assert shapes[0]["verts"] == (B, 6890, 3) and shapes[0]["projects"] == (B, 6890, 3) and shapes[0]["mask"] == (B, 6890)
+    assert shapes[0]["seg"] == (B, 48, 48, 32) and shapes[0]["smpl"] == (B, 86)
+    assert "verts" not in tr.decoder(tr.smpl_model(images), labels)      # the train decoder writes losses only
     assert sorted(os.listdir(tmp_path)) == sorted([name(0), name(2)])
     want = {k: v.clone() for k, v in tr.smpl_model.state_dict().items()}
     step_count = [int(st["step"]) for st in tr.opt.state_dict()["state"].values()][:1]

@@ -202,9 +202,12 @@ def test_decoder_options_are_validated_without_a_gpu():
     assert SMPLDecoder(None, loss=lf, outputs=()).loss is lf
     for bad in (dict(heads=()), dict(heads=("seg", "depth")), dict(outputs=("seg",)),
                 dict(heads=("silhouette",), loss=lf), dict(loss=lambda a, b: a),
-                dict(heads=("silhouette",), vertex_sampling=5)):
+                dict(heads=("silhouette",), vertex_sampling=5),
+                dict(grid_wh=0), dict(grid_wh=-3), dict(grid_wh=129), dict(grid_wh=0, loss=lf)):
         with pytest.raises(ValueError):
             SMPLDecoder(None, **bad)
+    # (a silhouette-only decoder computes no visibility mask: its grid_wh is not looked at)
+    assert SMPLDecoder(None, heads=("silhouette",), grid_wh=0).grid_wh == 0
     # the HIP path has no CPU fallback: a CPU tensor is refused, not silently computed elsewhere
     import torch
     with pytest.raises(RuntimeError):
