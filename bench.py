@@ -398,6 +398,22 @@ def launch_ranks(n, argv):
     return proc.returncode
 
 
+def _ranks_seen(dist, rank, world, dev, backend, own_ms):
+    """Every rank's (rank, device index, device name, its OWN ms per step before the MAX reduction), gathered on all
+    ranks: the N > 1 line shows that N distinct devices took part (`rccl_ranks_seen`) and how far apart they ran."""
+    if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+        mine = {"rank": rank, "device": int(torch.cuda.current_device()), "name": torch.cuda.get_device_name(dev),
+                "backend": backend if world > 1 else None, "ms_per_step": round(own_ms, 4)}
+    else:
+        mine = {"rank": rank, "device": "cpu", "name": "cpu (pid %d)" % os.getpid(),
+                "backend": backend if world > 1 else None, "ms_per_step": round(own_ms, 4)}
+    if dist is None or world == 1:
+        return [mine]
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return sorted(got, key=lambda d: d["rank"])
+
+
 def _max_over_ranks(dist, v, dev, backend):
     if dist is None:
         return v
@@ -501,6 +517,11 @@ def dry_run(args, rank, world):
     B, W = args.batch, args.wh
     seed = 1000 + rank
     x = torch.tensor(make_x(B, W, seed))
+    # fault rehearsal: BENCH_DRY_FAIL_RANK=r makes rank r die after the rendezvous - the launcher must then end the
+    # other ranks and the fresh child this was started as must exit non-zero, with no JSON line (tests/test_bench_launcher.py)
+    if os.environ.get("BENCH_DRY_FAIL_RANK", "") == str(rank):
+        sys.stderr.write("bench: rank %d fails on purpose (BENCH_DRY_FAIL_RANK)\n" % rank)
+        os._exit(3)
 
     def step():
         load_mean_set_cam_params(x, W)
@@ -557,8 +578,10 @@ def dry_run(args, rank, world):
             tleg["no_sync_step"] = {"ms_per_step": round(el2 / args.train_steps * 1e3, 3),
                                     "images_per_s": round(world * args.train_batch * args.train_steps / el2, 1)}
             tleg["allreduce_exposed_ms"] = round((el1 - el2) / args.train_steps * 1e3, 3)
+    seen = _ranks_seen(dist if world > 1 else None, rank, world, None, "gloo", mine / args.steps * 1e3)
     if rank == 0:
         print(json.dumps({
+            "rccl_ranks_seen": seen, "rank_ms_per_step": [d["ms_per_step"] for d in seen],
             "metric": "meshes/sec fwd+bwd (SMPL->48x48 31-part seg)", "value": round(world * B * args.steps / elapsed, 1),
             "unit": "meshes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -739,10 +762,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_ms = elapsed / args.steps * 1e3                 # this rank's own window, before the MAX over ranks
     if dist:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    seen = _ranks_seen(dist, rank, world, dev, backend, own_ms)
     # the spread: further windows of the same K steps, same bracketing (the first window above is `value`)
     windows = [elapsed / args.steps * 1e3]
     for _ in range(max(0, args.windows - 1)):
@@ -769,6 +794,8 @@ def main():
                                     "median": round(float(np.median(windows)), 4), "max": round(max(windows), 4),
                                     "note": "the first window is `ms_per_step` / `value`; boxes differ by +-4 %"},
             "build_id": _lib.build_id(),
+            "warmup_actual": nwarm * gsteps,
+            "rccl_ranks_seen": seen, "rank_ms_per_step": [d["ms_per_step"] for d in seen],
             "train_step": tleg,
             "config": {"workload": ("full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
                                     "projects_to_seg), BASELINE configs[2]" if variant_note is None

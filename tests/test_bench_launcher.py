@@ -46,6 +46,44 @@ def test_gpus_2_launches_two_ranks_itself():
     assert abs(t["allreduce_exposed_ms"] - (t["ddp_step"]["ms_per_step"] - t["no_sync_step"]["ms_per_step"])) < 2e-3
 
 
+def test_gpus_8_dry_run_is_the_eight_rank_protocol():
+    """The round-end scaling run's shape (N = 8, BASELINE configs[4]: global 1024 = 128 per GPU) rehearsed over gloo:
+    eight ranks started by bench.py itself, per-rank seeds, MAX reduction, the strong split 1024 -> 128, every rank
+    listed in `rccl_ranks_seen` with its own time, and the train leg's keys (train.py:196,205-210: 4 x num_gpus split)."""
+    r = _run(["--gpus", "8", "--steps", "3", "--warmup", "1", "--scaling", "strong", "--global-batch", "1024", "--dry-run",
+              "--train-batch", "8", "--train-steps", "2"], timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 1024 and d["config"]["meshes_per_gpu"] == 128
+    assert d["rank_seeds"] == [1000 + r_ for r_ in range(8)] and len(set(d["rank_input_checksums"])) == 8
+    elapsed = d["ms_per_step"] * d["steps"] * 1e-3
+    assert abs(elapsed - max(d["rank_elapsed_s"])) < 1e-9 and elapsed >= max(d["rank_work_s"])
+    assert d["rank_work_s"][7] > d["rank_work_s"][0]            # rank 7's stand-in step sleeps 8 x rank 0's
+    assert abs(d["value"] - 1024 * 3 / elapsed) < 0.5
+    seen = d["rccl_ranks_seen"]
+    assert [e["rank"] for e in seen] == list(range(8)) and len({e["name"] for e in seen}) == 8      # 8 distinct processes
+    assert all(e["backend"] == "gloo" for e in seen)
+    assert d["rank_ms_per_step"] == [e["ms_per_step"] for e in seen] and max(d["rank_ms_per_step"]) <= d["ms_per_step"] + 1e-3
+    t = d["train_step"]
+    assert t["ddp"] and t["n_gpus"] == 8 and t["global_batch"] == 64 and t["backend"] == "gloo"
+    for k in ("ddp_step", "no_sync_step"):
+        assert t[k]["ms_per_step"] > 0
+    assert "allreduce_exposed_ms" in t and t["allreduce_MiB"] > 0
+
+
+def test_a_failing_rank_fails_the_fresh_child():
+    """A rank that dies must not leave a JSON line or a zero exit code behind: bench.py started the ranks as a fresh
+    child process (never an exec) and returns that child's code."""
+    r = _run(["--gpus", "4", "--steps", "2", "--warmup", "0", "--batch", "4", "--dry-run", "--no-train-leg"],
+             env={"BENCH_DRY_FAIL_RANK": "2"}, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert b"rank 2 fails on purpose" in r.stderr
+
+
 def test_strong_scaling_splits_a_fixed_global_batch():
     r = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--scaling", "strong", "--global-batch", "10", "--dry-run",
               "--no-train-leg"])
@@ -69,6 +107,7 @@ def test_single_rank_default_needs_no_launcher():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.loads(r.stdout.decode().strip())
     assert d["n_gpus"] == 1 and d["rank_seeds"] == [1000]
+    assert [e["rank"] for e in d["rccl_ranks_seen"]] == [0] and d["rccl_ranks_seen"][0]["backend"] is None
 
 
 import pytest
@@ -92,6 +131,8 @@ def test_gpus_2_on_a_one_gpu_box():
     w = d["ms_per_step_windows"]
     assert w["n"] == 10 and w["min"] <= w["median"] <= w["max"] and w["min"] > 0
     assert len(d["build_id"]) == 64
+    assert [e["rank"] for e in d["rccl_ranks_seen"]] == [0, 1] and all(e["device"] == 0 for e in d["rccl_ranks_seen"])
+    assert len(d["rank_ms_per_step"]) == 2 and d["warmup_actual"] >= 200
     # the data-parallel train step (BASELINE configs[4]: ENet + IEF + decoder with both heads + both losses + Adam
     # under DistributedDataParallel): the step as trained, without the all-reduce, and the all-reduce's volume
     t = d["train_step"]

@@ -19,7 +19,8 @@ def _cfg(path):
 
 
 def test_fixtures_present():
-    assert len(GOLD) == 3
+    # W in {48, 64} x vertex_sampling in {None, 2, 5}
+    assert sorted((W, vs or 1) for W, vs in map(_cfg, GOLD)) == [(W, vs) for W in (48, 64) for vs in (1, 2, 5)]
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])

@@ -242,10 +242,13 @@ def test_decoder_at_large_raster_sizes(smpl_model, part_tables, W):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second HIP device")
-def test_ops_follow_their_operands_device(smpl_model):
+@pytest.mark.parametrize("blend_gemm", ["bf16x3", "f32"])
+def test_ops_follow_their_operands_device(smpl_model, blend_gemm, monkeypatch):
     """Operands on cuda:1 while cuda:0 is the current device: the launches must go to the operands' device
-    (every C-ABI call site enters a device guard), forward and backward."""
+    (every C-ABI call site enters a device guard), forward and backward - under both blend GEMM forms: each keeps a
+    per-DEVICE record of the LDS attribute it set on its kernels (blend3.hip, and since round 4 blend.hip too)."""
     from ilps_amd.decoder import SMPLDecoder
+    monkeypatch.setenv("SMPLR_BLEND_GEMM", blend_gemm)          # read when the constants are uploaded
     W, B = 48, 3
     x = make_x(B, W, seed=5)
     g = np.random.default_rng(5).normal(0, 1, (B, W, W, 32)).astype(np.float32)

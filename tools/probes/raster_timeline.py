@@ -52,3 +52,24 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def part_detail():
+    """Stamps 10..14 of the two-pixel kernel's stream scan (first non-empty part of every wave)."""
+    t = read_stamps("raster", 1152, 16)
+    ok = t[..., 14] > 0
+    n = t[..., 14][ok]
+    grp = ((t[..., 11] - t[..., 10]) & 0xFFFFFFFF)[ok]
+    rsc = ((t[..., 12] - t[..., 11]) & 0xFFFFFFFF)[ok]
+    fin = ((t[..., 13] - t[..., 12]) & 0xFFFFFFFF)[ok]
+    print("first part of a wave: groups median %d; group loop median %d clocks (%.0f per group), re-scan %d, finalise %d"
+          % (np.median(n), np.median(grp), np.median(grp / np.maximum(n, 1)), np.median(rsc), np.median(fin)))
+    for k in (1, 2, 3, 4, 6, 8, 12):
+        sel = n == k
+        if sel.sum() > 50:
+            print("  parts of %2d groups: %5d waves, loop %5.0f clocks (%.0f per group), re-scan %4.0f, finalise %4.0f"
+                  % (k, sel.sum(), np.median(grp[sel]), np.median(grp[sel]) / k, np.median(rsc[sel]), np.median(fin[sel])))
+
+
+if os.environ.get("TL_PARTS"):
+    part_detail()

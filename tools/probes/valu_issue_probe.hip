@@ -25,6 +25,21 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *stamps,
       if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(y[c]) : "v"(a2), "v"(b2));
       if (KIND == 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y[c]) : "v"(a2));
       if (KIND == 3) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+      if (KIND == 4) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+      if (KIND == 5) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+      if (KIND == 6) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(x[c]) : "v"(a), "v"(b) : "vcc");   // 2 instr
+      if (KIND == 7) asm volatile("v_exp_f32 %0, %0" : "+v"(x[c]));
+      if (KIND == 8) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[c]));
+      if (KIND == 9) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+      if (KIND == 10) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(y[c]) : "v"(a2));
+      if (KIND == 11) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+      if (KIND == 12) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+      if (KIND == 13) asm volatile("v_mov_b32 %0, %1" : "+v"(x[c]) : "v"(a));
+      if (KIND == 14) asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(x[c]) : "v"(b));     // (du, du, t): two distinct sources
+      if (KIND == 15) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(y[c]) : "v"(a2)); // the loop's shape: fma(du, du, t)
+      if (KIND == 16) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+      if (KIND == 17) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+      if (KIND == 18) asm volatile("v_min_f32 %0, %0, %1\n\tv_min_f32 %0, %0, %2" : "+v"(x[c]) : "v"(a), "v"(b));   // 2 instr
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -45,7 +60,7 @@ static int cmp(const void *a, const void *b) {
 template <int KIND>
 static void run(const char *name, float *out, unsigned long long *stamps, unsigned long long *h) {
   const int iters = 256;
-  for (int wps = 1; wps <= 4; wps <<= 1) {
+  for (int wps = 1; wps <= 8; wps <<= 1) {
     const int blocks = 256 * wps;                       // wps blocks of 4 waves per CU -> wps waves per SIMD
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, stamps, iters, 1.0001f, 0.5f);
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, stamps, iters, 1.0001f, 0.5f);
@@ -66,12 +81,27 @@ static void run(const char *name, float *out, unsigned long long *stamps, unsign
 
 int main() {
   float *out; unsigned long long *stamps;
-  hipMalloc(&out, 1024 * 256 * sizeof(float));
-  hipMalloc(&stamps, 1024 * 8 * sizeof(unsigned long long));
-  unsigned long long *h = (unsigned long long *)malloc(1024 * 8 * sizeof(unsigned long long));
+  hipMalloc(&out, 2048 * 256 * sizeof(float));
+  hipMalloc(&stamps, 2048 * 8 * sizeof(unsigned long long));
+  unsigned long long *h = (unsigned long long *)malloc(2048 * 8 * sizeof(unsigned long long));
   run<0>("v_fma_f32", out, stamps, h);
   run<1>("v_pk_fma_f32", out, stamps, h);
   run<2>("v_pk_add_f32", out, stamps, h);
   run<3>("v_min3_f32", out, stamps, h);
+  run<4>("v_min_f32", out, stamps, h);
+  run<5>("v_sub_f32", out, stamps, h);
+  run<6>("cmp+cndmask(x2)", out, stamps, h);
+  run<7>("v_exp_f32", out, stamps, h);
+  run<8>("v_sqrt_f32", out, stamps, h);
+  run<9>("v_min3_u32", out, stamps, h);
+  run<10>("v_pk_mul_f32", out, stamps, h);
+  run<11>("v_mul_u32_u24", out, stamps, h);
+  run<12>("v_min_u32", out, stamps, h);
+  run<13>("v_mov_b32", out, stamps, h);
+  run<14>("v_fma(x,x,b)", out, stamps, h);
+  run<15>("pk_fma(a,a,y)", out, stamps, h);
+  run<16>("v_max3_f32", out, stamps, h);
+  run<17>("v_med3_f32", out, stamps, h);
+  run<18>("v_min_f32(x2)", out, stamps, h);
   return 0;
 }
