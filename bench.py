@@ -205,7 +205,7 @@ def raster_roofline(x, consts, pt, W, stages):
     flop = pairs * 7.0
     ach = flop / t_ras / 1e12
     brute = float(W * W) * pt.K * B                                  # every pixel x every part vertex
-    out = {"kernel": "raster_fwd_kernel (smplr_seg_raster)", "bound": "mfma", "pipe": "fp32 VALU (vector peak = fp32 matrix peak)",
+    out = {"kernel": "raster2_fwd_kernel (smplr_seg_raster; two pixels per lane since round 4)", "bound": "mfma", "pipe": "fp32 VALU (vector peak = fp32 matrix peak)",
            "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4),
            "traffic": None, "launch_us": round(t_ras * 1e6, 2), "launch_us_isolated_replay": round(t_iso * 1e6, 2),
            "launch_us_how": "median over 60 launches inside an eager step of the step's own seven kernels, HIP events ON the "
@@ -222,7 +222,7 @@ def raster_roofline(x, consts, pt, W, stages):
     if os.path.exists(tf) and B == 128 and W == 48:
         try:
             tj = json.load(open(tf))
-            k = next((v for kn, v in tj["kernels"].items() if kn.startswith("raster_fwd_kernel")), {})
+            k = next((v for kn, v in tj["kernels"].items() if kn.startswith(("raster2_fwd_kernel", "raster_fwd_kernel"))), {})
             # the committed counter passes are stamped with the library they were taken on
             out["profile_build_id_matches"] = tj.get("build_id") == _lib.build_id()
             out["traffic"] = k.get("hbm_bytes_per_launch")
@@ -239,13 +239,54 @@ def raster_roofline(x, consts, pt, W, stages):
                                       round(q["issue_cycles_packed"] * q["SQ_INSTS_VALU"] / cyc, 3)]
             out["valu_source"] = ("profiles/raster_sq.json: valu_active_frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) and "
                                   "valu_issue_frac = SQ_INSTS_VALU x [%.2f, %.2f] cycles per wave64 instruction (measured issue "
-                                  "cost of a plain and of a packed / three-operand fp32 instruction at 4 waves per SIMD, %s; "
+                                  "cost of a plain and of a packed / three-operand fp32 instruction at 8 waves per SIMD, %s; "
                                   "the kernel mixes both), each over %d SIMDs x %.2f us x %.1f GHz nominal"
-                                  % (q["issue_cycles_plain"], q["issue_cycles_packed"], "profiles/r02_valu_issue_probe.txt",
+                                  % (q["issue_cycles_plain"], q["issue_cycles_packed"], "profiles/r04_valu_issue_probe.txt",
                                      q["simds"], q["kernel_us"], q["clock_hz"] / 1e9))
         except Exception:
             pass
     return out
+
+
+def size_leg(x, consts, W, vs, dev):
+    """One of the reference's OTHER shipped sizes through the headline's step (decoder fwd+bwd at the batch of `x`,
+    ten steps per HIP-graph replay, HIP events): W = 64 is what train.py:320-321 and predict.py:129-136 call,
+    vertex_sampling 2 / 5 what projects_to_seg.py:18-24 and profiling_renderer.py:26-28 offer.  Adds the rasteriser's
+    own launch time (hipExtLaunchKernel events ON the launch, median of 30, inside bin -> raster pairs), the
+    far-reaching records per mesh it walks and its fraction of the fp32 vector peak, as `roofline` does for the headline."""
+    import ctypes
+    B = x.shape[0]
+    pt = ops.get_part_table(vs, dev, consts.V)
+    st = torch.cuda.current_stream()
+    dseg = torch.randn(B, W, W, 32, device=dev)
+
+    def step():
+        xg = x.detach().requires_grad_(True)
+        o_ = ops.DecoderFn.apply(xg, consts, 4, W, vs, pt, 64, True, False, 1)
+        o_[3].backward(dseg)
+    step()
+    ms = graph_time_ms(step, 10, st)
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, consts)
+    proj = ops._skin_fwd(ops._blend_fwd(coef, consts, B), A, consts, cam=x, vertex_sampling=vs)[1]
+    mask = torch.empty(B, pt.VP, device=dev)
+    ws, rec = ops._seg_bin(proj, mask, W, pt, grid_wh=64)
+    seg, arg = ops._seg_raster(ws, rec, B, W, pt)
+    lib_, kms, kern = _lib.load(), ctypes.c_float(0.0), []
+    for i in range(35):
+        ops._seg_bin(proj, mask, W, pt, grid_wh=64, rec=rec, ws=ws)
+        _lib.check(lib_.smplr_seg_raster_timed(B, W, pt.P, pt.K, _lib.ptr(ws), _lib.ptr(rec), _lib.ptr(seg), _lib.ptr(arg),
+                                               ctypes.byref(kms), _lib.stream()), "smplr_seg_raster_timed")
+        if i >= 5:
+            kern.append(float(kms.value))
+    t_ras = float(np.median(kern)) * 1e-3
+    far = (mask[:, pt.part_pos.long()] <= 208.0).sum(dim=1).double()
+    pairs = float(far.sum().item()) * W * W
+    ach = pairs * 7.0 / t_ras / 1e12
+    return {"img_wh": W, "vertex_sampling": vs, "meshes": B, "ms_per_step": round(ms, 4),
+            "meshes_per_s": round(B / (ms * 1e-3), 1), "far_records_per_mesh": round(float(far.mean().item()), 1),
+            "far_records_max": int(far.max().item()), "part_vertices": int(pt.K),
+            "raster_us": round(t_ras * 1e6, 2), "raster_tflops": round(ach, 3), "raster_frac": round(ach / FP32_PEAK_TFLOPS, 4),
+            "executed_pairs_per_launch": int(pairs), "algorithmic_pairs_per_launch": int(float(W * W) * pt.K * B)}
 
 
 def _cpu_info():
@@ -478,6 +519,17 @@ def train_leg(args, rank, world, dev, dist, backend, model, W):
                                                 "images_per_s": round(world * per * steps / el, 1)}
     out["images_per_s"] = round(world * per * steps / el, 1)
     out["ms_per_step"] = round(el / steps * 1e3, 3)
+    # where the step's time goes: HIP events between its sections (median of 5 steps; every rank runs them, rank 0 reports)
+    try:
+        sp = [tr.step_timed(*data) for _ in range(5)]
+        for k in ("encoder_ms", "decoder_ms", "optimizer_ms"):
+            out[k] = round(float(np.median([d[k] for d in sp])), 3)
+        out["split_note"] = ("encoder = ENet + IEF forward and backward (stock torch / MIOpen; under DDP with the all-reduce "
+                             "it overlaps), decoder = HIP decoder + losses forward and backward, optimizer = zero_grad + Adam")
+        out["conv_backend"] = {"cudnn_benchmark": bool(torch.backends.cudnn.benchmark),
+                               "MIOPEN_FIND_MODE": os.environ.get("MIOPEN_FIND_MODE")}
+    except Exception as e:
+        out["split_error"] = "%s: %s" % (type(e).__name__, e)
     if world > 1:
         def nosync_step():
             with tr.net.no_sync():
@@ -603,6 +655,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="meshes per GPU")
     ap.add_argument("--wh", type=int, default=48)
+    ap.add_argument("--vertex-sampling", type=int, default=1, choices=[1, 2, 5],
+                    help="the default step at the reference's vertex_sampling 2 / 5 (profiling passes; 1 = the headline)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
     ap.add_argument("--step", default="default",
                     choices=["default", "seg_only", "fused_loss", "unfused_loss", "both_heads", "silhouette_only"],
@@ -666,14 +720,15 @@ def main():
     B, W = args.batch, args.wh
     model = synthetic_smpl_model(1234)
     consts = ops.SMPLConstants.from_model(model, dev)
-    pt = ops.get_part_table(1, dev, consts.V)
+    vs_main = int(args.vertex_sampling)
+    pt = ops.get_part_table(vs_main, dev, consts.V)
     x = torch.tensor(make_x(B, W, 1000 + rank), device=dev)      # resident in HBM before timing
     gen = torch.Generator(device="cpu").manual_seed(rank)
     dseg = torch.randn(B, W, W, 32, generator=gen).to(dev)
 
     def step():
         xg = x.detach().requires_grad_(True)
-        verts, proj, mask, seg, silh, jt, _ls = ops.DecoderFn.apply(xg, consts, 4, W, 1, pt, 64, True, False,
+        verts, proj, mask, seg, silh, jt, _ls = ops.DecoderFn.apply(xg, consts, 4, W, vs_main, pt, 64, True, False,
                                                                args.streams)
         seg.backward(dseg)
         return xg.grad
@@ -772,6 +827,20 @@ def main():
     windows = [elapsed / args.steps * 1e3]
     for _ in range(max(0, args.windows - 1)):
         windows.append(_timed_steps(run, 0, nrun, dist, dev, backend, torch.cuda.synchronize) / args.steps * 1e3)
+    # the same K steps with ONE step per graph launch: what a caller gets who replays the decoder's graph once per
+    # training step, between two encoder steps (the headline replays `gsteps` decoder steps per launch)
+    ms_graph1 = None
+    if mode == "graph" and gsteps > 1:
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                step()
+            ms_graph1 = _timed_steps(g1.replay, 20, args.steps, dist, dev, backend, torch.cuda.synchronize) / args.steps * 1e3
+            del g1
+        except Exception as e:
+            sys.stderr.write("bench: one-step graph failed (%s)\n" % e)
+    elif mode == "graph":
+        ms_graph1 = windows[0]
     # the design's one collective: the data-parallel train step (every rank takes part)
     tleg = None
     if not args.no_train_leg:
@@ -795,12 +864,13 @@ def main():
                                     "note": "the first window is `ms_per_step` / `value`; boxes differ by +-4 %"},
             "build_id": _lib.build_id(),
             "warmup_actual": nwarm * gsteps,
+            "ms_per_step_graph1": None if ms_graph1 is None else round(ms_graph1, 4),
             "rccl_ranks_seen": seen, "rank_ms_per_step": [d["ms_per_step"] for d in seen],
             "train_step": tleg,
             "config": {"workload": ("full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
                                     "projects_to_seg), BASELINE configs[2]" if variant_note is None
                                     else "VARIANT --step %s (not the headline): %s" % (args.step, variant_note)),
-                       "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "verts": 6890,
+                       "meshes_per_gpu": B, "global_batch": B * world, "img_wh": W, "vertex_sampling": vs_main, "verts": 6890,
                        "params_per_mesh": 86, "launch": mode, "steps_per_graph_launch": gsteps,
                        "concurrent_chunks": args.streams,
                        "blend_gemm": ("bf16x3: fp32 operands as 3 bf16 terms (24 significant bits), 6 partial "
@@ -898,6 +968,36 @@ def main():
                 line["aux"]["predict_B1"] = {"ms_per_image": round(t_p, 3), "decoder_forward_us": round(t_d * 1e3, 1),
                                              "note": "encoder + regressor + decoder forward for one image, eager launches "
                                                      "(host-bound); decoder_forward_us = its 5 kernels replayed from a graph"}
+                # the decoder's side of that eager forward by binding: one at::Tensor op (torch.ops.smplraster.decoder_fwd,
+                # what SMPLDecoder runs without gradients) against the autograd node's ctypes calls - host wall time per call
+                try:
+                    x1 = x[:1].contiguous()
+
+                    def host_us(n=200):
+                        with torch.no_grad():
+                            for _ in range(20):
+                                dec1(x1)
+                            torch.cuda.synchronize()
+                            t0h = time.perf_counter()
+                            for _ in range(n):
+                                dec1(x1)
+                            torch.cuda.synchronize()
+                        return (time.perf_counter() - t0h) / n * 1e6
+                    prev = os.environ.get("SMPLR_TORCH_OPS")
+                    os.environ["SMPLR_TORCH_OPS"] = "0"
+                    us_ct = host_us()
+                    t_p0 = event_time_ms(lambda: predict_batch(reg, dec1, img), 10, torch.cuda.current_stream())
+                    os.environ["SMPLR_TORCH_OPS"] = "1"
+                    us_op = host_us()
+                    if prev is None:
+                        del os.environ["SMPLR_TORCH_OPS"]
+                    else:
+                        os.environ["SMPLR_TORCH_OPS"] = prev
+                    line["aux"]["predict_B1"].update({"decoder_eager_us_ctypes": round(us_ct, 1),
+                                                      "decoder_eager_us_torch_op": round(us_op, 1),
+                                                      "ms_per_image_ctypes_decoder": round(t_p0, 3)})
+                except Exception as e:
+                    line["aux"]["predict_B1"]["binding_error"] = "%s: %s" % (type(e).__name__, e)
                 try:
                     from ilps_amd.inference import GraphedPredictor
                     gp = GraphedPredictor(reg, dec1, img)
@@ -934,6 +1034,14 @@ def main():
                 line["aux"]["reference_renderer_profile_workload"] = entry
             except Exception as e:
                 line["aux"]["reference_renderer_profile_workload"] = {"error": str(e)}
+            # the reference's other shipped sizes (VERDICT r03 missing #2, #3): W = 64 and vertex_sampling 2 / 5
+            line["aux"]["reference_sizes"] = {}
+            for nm, (W_, vs_) in (("w64", (64, 1)), ("w48_vs2", (48, 2)), ("w48_vs5", (48, 5)), ("w64_vs5", (64, 5))):
+                try:
+                    xs_ = x if W_ == W else torch.tensor(make_x(B, W_, 1000 + rank), device=dev)
+                    line["aux"]["reference_sizes"][nm] = size_leg(xs_, consts, W_, vs_, dev)
+                except Exception as e:
+                    line["aux"]["reference_sizes"][nm] = {"error": "%s: %s" % (type(e).__name__, e)}
             # silhouette rasteriser (part of configs[4]'s second loss), same meshes
             c0s = ops._pose_fwd(x, 4, consts)
             pjs = ops._skin_fwd(ops._blend_fwd(c0s[0], consts, x.shape[0]), c0s[3], consts, cam=x)[1]

@@ -1117,14 +1117,17 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   const float4 *Gn = G + (size_t)n * S;
   const int *goffn = goff + (size_t)n * (P + 2);
   const int C = P + 1;
-  // merge / write-out items: item e = it * NT + tid is tile pixel e / 8 (= 2 x pair-lane + row of the pair), channels 4 (e % 8) ..
-  constexpr int NIT = RTS * 8 / NT;
-  const int sub = tid & 7;
+  // merge / write-out items: item e = it * NT + tid is tile pixel e / 4 (= 2 x pair-lane + row of the pair); its lane
+  // sub4 = e % 4 takes the channel chunks sub4 and sub4 + 4 (channels 4 sub4 .. and 16 + 4 sub4 ..): four lanes per
+  // pixel, ONE item per thread at 1 024 threads - the per-item fixed cost (pixel decode, list bounds, addresses) of
+  // raster_fwd_kernel's 8-lanes-per-pixel form once per 8 channels instead of once per 4
+  constexpr int NIT = RTS * 4 / NT;
+  const int sub = tid & 3;
   int l0a[NIT], l1a[NIT], qqa[NIT];
   int lab[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int pl = (it * NT + tid) >> 3;
+    const int pl = (it * NT + tid) >> 2;
     const int Li = tile * PLN + (pl >> 1);
     const int Lc = min(Li, nl - 1);
     const int Qi = (int)(((unsigned)Lc * wmagic) >> 24), ci = Lc - Qi * W;
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   SMPLR_TL_STAMP(2);
   __syncthreads();
   SMPLR_TL_STAMP(3);
-  // the first 8 local records of each of this lane's merge pixels are fetched now and used after the pair loop
+  // the first 4 local records of each of this lane's merge pixels are fetched now and used after the pair loop
   uint2 lr0[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) lr0[it] = lrecn[min(l0a[it] + sub, K - 1)];
@@ -1255,13 +1258,28 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   SMPLR_TL_STAMP(4);
   __syncthreads();
   SMPLR_TL_STAMP(5);
-  // merge of the local records and write-out: raster_fwd_kernel's, item for item (see there)
+  // Merge of the local records and write-out.  raster_fwd_kernel's scheme (LDS atomic max on the score bits, ties keep
+  // the earlier winner, global before local) with FOUR lanes per pixel: a lane takes every 4th record of the pixel's list,
+  // then the channel chunks sub and sub + 4.  The background's sum keeps raster_fwd_kernel's tree bit for bit: chunk sums
+  // s_j = (v0 + v1) + (v2 + v3); Qlo = (s0 + s1) + (s2 + s3), Qhi = (s4 + s5) + (s6 + s7) by two quad exchanges each
+  // (there: the 8-lane tree's first two steps); sum = Qlo + Qhi (there: lane 0 + lane 7 of the half-mirror step, and
+  // fp32 addition commutes).
+  auto quad_sum = [](float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));    // quad_perm 1,0,3,2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));    // quad_perm 2,3,0,1
+    return v;
+  };
+  auto quad_max = [](float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    return v;
+  };
   float den_[NIT], st_[NIT], eg_[NIT];
   unsigned po_[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = it * NT + tid;
-    const int pl = e >> 3, c4 = (e & 7) * 4;
+    const int pl = e >> 2, cA = sub * 4, cB = 16 + sub * 4;
     {
       int *rowS = reinterpret_cast<int *>(&sS[pl * SLD + 1]);
       short *rowA = &sA[pl * ALD + 1];
@@ -1269,7 +1287,7 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
       int i = l0a[it] + sub;
       uint2 rec = lr0[it];
       while (__any(i < l1)) {
-        const uint2 nxt = lrecn[min(i + 8, K - 1)];        // next step's record, in flight during this one
+        const uint2 nxt = lrecn[min(i + 4, K - 1)];        // next step's record, in flight during this one
         if (i < l1) {
           const int sc = __float_as_int(fast_exp_neg(__uint_as_float(rec.x)));
           const int p = (int)rec.y;
@@ -1278,42 +1296,47 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
           if (old < sc && fin == sc) rowA[p] = (short)(lbase + i);
         }
         rec = nxt;
-        i += 8;
+        i += 4;
       }
     }
-    const float *ts = &sS[pl * SLD + c4];
-    const short *ta = &sA[pl * ALD + c4];
-    float v[4];
-    short a[4];
+    const float *ts = &sS[pl * SLD];
+    const short *ta = &sA[pl * ALD];
+    float va[4], vb[4];
+    short aa[4], ab[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      v[t] = ts[t];
-      a[t] = ta[t];
+      va[t] = ts[cA + t];
+      vb[t] = ts[cB + t];
+      aa[t] = ta[cA + t];
+      ab[t] = ta[cB + t];
     }
-    if (c4 == 0) v[0] = 0.0f;                              // the tile holds nothing for channel 0 ...
+    if (sub == 0) va[0] = 0.0f;                            // the tile holds nothing for channel 0 ...
     if (C != 32) {                                         // ... nor for slots >= C (block-uniform: not the reference's 31 parts)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        if (c4 + t >= C) {
-          v[t] = 0.0f;
-          a[t] = (short)-1;
-        }
+        if (cA + t >= C) { va[t] = 0.0f; aa[t] = (short)-1; }
+        if (cB + t >= C) { vb[t] = 0.0f; ab[t] = (short)-1; }
       }
     }
-    const float sum = sum8_dpp((v[0] + v[1]) + (v[2] + v[3]));   // over the pixel's parts (all lanes take part)
+    const float sum = quad_sum((va[0] + va[1]) + (va[2] + va[3])) + quad_sum((vb[0] + vb[1]) + (vb[2] + vb[3]));
     float vmx = 0.0f;
-    if (lo.vmax) vmx = max8_dpp(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));   // (block-uniform; channel 0 holds 0 here)
-    if (c4 == 0) {
-      v[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);         // background (:61-64)
-      a[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;         // clip pass-through gate
+    if (lo.vmax)                                           // (block-uniform; channel 0 holds 0 here)
+      vmx = quad_max(fmaxf(fmaxf(fmaxf(va[0], va[1]), fmaxf(va[2], va[3])), fmaxf(fmaxf(vb[0], vb[1]), fmaxf(vb[2], vb[3]))));
+    if (sub == 0) {
+      va[0] = 1.0f - fminf(fmaxf(sum, 0.0f), 1.0f);        // background (:61-64)
+      aa[0] = (sum >= 0.0f && sum <= 1.0f) ? 1 : 0;        // clip pass-through gate
     }
     const int qq = qqa[it];
     if (LOSS) {                                            // (C == 32: checked by the launcher; all lanes take part)
-      den_[it] = sum8_dpp((__expf(v[0]) + __expf(v[1])) + (__expf(v[2]) + __expf(v[3])));
+      den_[it] = quad_sum((__expf(va[0]) + __expf(va[1])) + (__expf(va[2]) + __expf(va[3]))) +
+                 quad_sum((__expf(vb[0]) + __expf(vb[1])) + (__expf(vb[2]) + __expf(vb[3])));
       const int t = lab[it];
-      const float vt = (t & 2) ? ((t & 1) ? v[3] : v[2]) : ((t & 1) ? v[1] : v[0]);
-      st_[it] = sum8_dpp(c4 == (t & ~3) ? vt : 0.0f);      // the labelled class' score in all 8 lanes (+ exact zeros)
-      const float eg = a[0] ? __expf(v[0]) : -1.0f;
+      const float vta = (t & 2) ? ((t & 1) ? va[3] : va[2]) : ((t & 1) ? va[1] : va[0]);
+      const float vtb = (t & 2) ? ((t & 1) ? vb[3] : vb[2]) : ((t & 1) ? vb[1] : vb[0]);
+      // the labelled class' score in all 4 lanes (+ exact zeros)
+      st_[it] = quad_sum(cA == (t & ~3) ? vta : 0.0f) + quad_sum(cB == (t & ~3) ? vtb : 0.0f);
+      // the background's exp where the clip's gate is open, else a negative number, from the pixel's lane 0 to all 4
+      const float eg = aa[0] ? __expf(va[0]) : -1.0f;
       eg_[it] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(eg), 0x00, 0xF, 0xF, false));
     }
     unsigned po = ~0u;
@@ -1322,24 +1345,30 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
       po = (unsigned)((W - 1 - rr) * W + cc);              // rows flipped (:68); mesh base + 32-bit offset
     }
     if (LOSS) po_[it] = po;
-    if (qq >= 0 && c4 < C) {
-      if (lo.vmax && c4 == 0) lo.vmax[(size_t)n * npix + po] = vmx;
-      float *so = seg + (size_t)n * npix * C + (po * (unsigned)C + (unsigned)c4);
+    if (qq >= 0) {
+      if (lo.vmax && sub == 0) lo.vmax[(size_t)n * npix + po] = vmx;
+      float *so = seg + (size_t)n * npix * C + po * (unsigned)C;
       if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
-      } else if (c4 + 3 < C && (C & 3) == 0) {
-        SMPLR_OUT_STORE(reinterpret_cast<f32x4 *>(so), (f32x4{v[0], v[1], v[2], v[3]}));
+      } else if (C == 32) {
+        SMPLR_OUT_STORE(reinterpret_cast<f32x4 *>(so + cA), (f32x4{va[0], va[1], va[2], va[3]}));
+        SMPLR_OUT_STORE(reinterpret_cast<f32x4 *>(so + cB), (f32x4{vb[0], vb[1], vb[2], vb[3]}));
       } else {
-        for (int t = 0; t < 4; ++t)
-          if (c4 + t < C) so[t] = v[t];
+        for (int t = 0; t < 4; ++t) {
+          if (cA + t < C) so[cA + t] = va[t];
+          if (cB + t < C) so[cB + t] = vb[t];
+        }
       }
+      short *ao = arg + (size_t)n * npix * 32 + po * 32u;
       short4 o4;
-      o4.x = a[0]; o4.y = a[1]; o4.z = a[2]; o4.w = a[3];
-      *reinterpret_cast<short4 *>(arg + (size_t)n * npix * 32 + (po * 32u + (unsigned)c4)) = o4;
+      o4.x = aa[0]; o4.y = aa[1]; o4.z = aa[2]; o4.w = aa[3];
+      *reinterpret_cast<short4 *>(ao + cA) = o4;
+      o4.x = ab[0]; o4.y = ab[1]; o4.z = ab[2]; o4.w = ab[3];
+      *reinterpret_cast<short4 *>(ao + cB) = o4;
     }
   }
   if (LOSS) {
-    // the per-pixel end of the loss once for all merge steps of the lane: lane `it` of a pixel's 8 finishes step `it`
-    static_assert(!LOSS || NIT <= 4, "the background's lane reaches its quad only");
+    // the per-pixel end of the loss once for all merge steps of the lane: lane `it` of a pixel's 4 finishes step `it`
+    static_assert(!LOSS || NIT <= 4, "a pixel has four lanes");
     float den = den_[0], st = st_[0], eg = eg_[0], w = wlab[0];
     int t = lab[0];
     unsigned po = po_[0];
@@ -1512,6 +1541,101 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
   else seg_flush(acc, cur, sx, sy);
 }
 
+// The FAST row walk (C == 32, W = 8 NB) as a software pipeline over its NB batches of SB_U pixels (round 4).  The
+// in-kernel stamps of round 2 (profiles/r02_timelines.txt) show a batch as two halves of equal length: ~2.0 k clocks
+// of memory latency (its arg / dseg rows, then the DEPENDENT gather of the arg-min records) with the vector unit idle,
+// and ~2.2 k clocks of vector work (score, run sums, flushes) with nothing in flight - at three waves per SIMD neither
+// half hides the other.  Here batch b + 2's rows are requested and batch b + 1's records gathered BEFORE batch b is
+// summed: a wave's walk is as long as its vector work alone.  Fully unrolled (W = 48: 8 batches of 6 pixels, W = 64: 16 of 4 - the registers of three batches in flight
+// beside the walk's own 59 must stay within the 168 a 768-thread block allows), so the three
+// batches in flight are register names, not copies.  Same arithmetic, same order of flushes as seg_bwd_row.
+template <int U, int NB, bool DET>
+__device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg, const short *__restrict__ arg,
+                                                 const float4 *__restrict__ R, int rbytes, float *acc, size_t row0,
+                                                 int ch, float fr, float scale, const int *pa, const float *pg) {
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+  const bool chok = ch >= 1;
+  const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(R), 0, rbytes, 0x00020000);
+  const short *arow = arg + row0 * 32 + ch;
+  const float *grow = dseg + row0 * 32 + ch;
+  int a[NB][U];
+  float g[NB][U];
+  float4 rv[NB][U];
+  static_assert(U <= SB_U, "the first batch comes from the SB_U pixels requested at kernel entry");
+  int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
+  float sx = 0.0f, sy = 0.0f;
+#ifdef SMPLR_TL
+  constexpr int W = U * NB;                      // (the stamp macro's window test)
+#endif
+  SMPLR_TL_ROW
+  // rows of batch b_ (arg-min slots + cotangents)
+  // (the batch offset passes through an empty asm with a memory clobber: the loads are speculatable, and unrolled the
+  // compiler otherwise hoists EVERY batch's loads to the top of the function - 185 spilled registers)
+#define SMPLR_SB_LOAD(b_)                                                   \
+  {                                                                         \
+    int o_ = (b_) * U * 32;                                              \
+    asm volatile("" : "+v"(o_) : : "memory");                               \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                         \
+      a[b_][u] = arow[o_ + u * 32];                                         \
+      g[b_][u] = grow[o_ + u * 32];                                         \
+    }                                                                       \
+  }
+  // the channel-0 lane's gate and gradient broadcast, then the dependent gather of batch b_'s arg-min records
+#define SMPLR_SB_GATHER(b_)                                                                                     \
+  asm volatile("" : : : "memory");                                                                              \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                               \
+    g[b_][u] = g[b_][u] - __shfl((a[b_][u] == 1) ? g[b_][u] : 0.0f, 0, 32);                                     \
+    rv[b_][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, a[b_][u] * 16, 0, 0));    \
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {                  // batch 0 was requested at kernel entry (its first U pixels)
+    a[0][u] = pa[u];
+    g[0][u] = pg[u];
+  }
+  if (NB > 1) { SMPLR_SB_LOAD(1) }
+  SMPLR_SB_GATHER(0)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    // (scheduling fences: unrolled, the compiler would otherwise hoist EVERY batch's loads to the top - 185 spills)
+    __builtin_amdgcn_sched_barrier(0);
+    if (b + 2 < NB) { SMPLR_SB_LOAD(b + 2) }
+    if (b + 1 < NB) { SMPLR_SB_GATHER(b + 1) }
+    __builtin_amdgcn_sched_barrier(0);
+    SMPLR_TL_STAMP(3 + b * 2);
+    if (chok) {                                  // channel 0 has no part (its lanes have served the broadcasts above)
+      // (the batch's first column through an empty asm: as compile-time constants the 48 columns became 48 packed
+      // {-column, -row} operands hoisted out of the window loop - and spilled)
+      float fb = (float)(b * U);
+      asm volatile("" : "+v"(fb));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float fc = fb + (float)u;
+        const float du = rv[b][u].x - fc, dv = rv[b][u].y - fr;
+        const float d2 = fmaf(du, du, dv * dv);
+        const float t = d2 * rv[b][u].z;
+        const float r = __builtin_amdgcn_rsqf(fmaxf(t, 1e-37f));      // (see seg_bwd_row: m d = t r, m / d = m^2 r)
+        const float kk = (-g[b][u] * fast_exp_neg(t * r)) * (rv[b][u].z * r);
+        const bool on = kk != 0.0f;
+        if (on && a[b][u] != cur) {
+          if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+          else seg_flush(acc, cur, sx, sy);
+          cur = a[b][u];
+          sx = 0.0f;
+          sy = 0.0f;
+        }
+        sx = fmaf(kk, du, sx);
+        sy = fmaf(kk, dv, sy);
+      }
+    }
+    SMPLR_TL_STAMP(4 + b * 2);
+  }
+#undef SMPLR_SB_LOAD
+#undef SMPLR_SB_GATHER
+  if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+  else seg_flush(acc, cur, sx, sy);
+}
+
 // The row walk when the loss head's backward is fused in (seg_bwd_kernel<.., LOSS = true>): d loss / d score of a
 // channel is rebuilt per pixel from what the forward's loss epilogue left (raster_fwd_kernel<true>),
 //   g_c = A (delta_ct - softmax_c) - g_background,   A = dloss q_t softmax_t,   softmax_c = exp(score_c) / sum exp,
@@ -1618,12 +1742,95 @@ __device__ __forceinline__ void seg_bwd_row_loss(LossIn li, const short *__restr
   else seg_flush(acc, cur, sx, sy);
 }
 
+// seg_bwd_row_pipe for the fused loss head: per pixel the lane needs its arg-min slot (2 B), dloss (4 B) and stats
+// (16 B, the same for all 32 lanes of the pixel's group) and then its record.  Three stages in flight: rows of batch
+// b + 2 requested; batch b + 1's rows folded into (c1, c2) - g_c = c1 - c2 exp(score_c), see seg_bwd_batch_loss - and
+// its records gathered; batch b summed.  Four pixels per batch keep that within the block's 168 registers.
+template <int U, int NB, bool DET>
+__device__ __forceinline__ void seg_bwd_row_loss_pipe(LossIn li, const short *__restrict__ arg, const float4 *__restrict__ R,
+                                                      int rbytes, float *acc, size_t row0, int ch, float fr, float scale,
+                                                      const int *pa, const float *pg) {
+  unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
+  const bool chok = ch >= 1;
+  const __amdgpu_buffer_rsrc_t rrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(R), 0, rbytes, 0x00020000);
+  const short *arow = arg + row0 * 32 + ch;
+  const float *drow = li.dloss + row0;
+  const float4 *srow = li.stats + row0;
+  static_assert(U <= SB_U, "the first batch comes from the SB_U pixels requested at kernel entry");
+  int a[NB][U];
+  float dl[NB][U], c1[NB][U], c2[NB][U];
+  float4 st[NB][U], rv[NB][U];
+  int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
+  float sx = 0.0f, sy = 0.0f;
+#define SMPLR_SBL_LOAD(b_, first_)                                          \
+  {                                                                         \
+    int o_ = (b_) * U;                                                      \
+    asm volatile("" : "+v"(o_) : : "memory");                               \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                         \
+      if (first_) {                                                         \
+        a[b_][u] = pa[u];                                                   \
+        dl[b_][u] = pg[u];                                                  \
+      } else {                                                              \
+        a[b_][u] = arow[(o_ + u) * 32];                                     \
+        dl[b_][u] = drow[o_ + u];                                           \
+      }                                                                     \
+      st[b_][u] = srow[o_ + u];                                             \
+    }                                                                       \
+  }
+#define SMPLR_SBL_GATHER(b_)                                                                                    \
+  asm volatile("" : : : "memory");                                                                              \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                               \
+    c1[b_][u] = dl[b_][u] * ((__float_as_int(st[b_][u].w) == ch ? st[b_][u].z : 0.0f) - st[b_][u].y);           \
+    c2[b_][u] = dl[b_][u] * st[b_][u].x;                                                                        \
+    if (!chok) a[b_][u] = -1;                                                                                   \
+    rv[b_][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, a[b_][u] * 16, 0, 0));    \
+  }
+  SMPLR_SBL_LOAD(0, true)
+  if (NB > 1) { SMPLR_SBL_LOAD(1, false) }
+  SMPLR_SBL_GATHER(0)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (b + 2 < NB) { SMPLR_SBL_LOAD(b + 2, false) }
+    if (b + 1 < NB) { SMPLR_SBL_GATHER(b + 1) }
+    __builtin_amdgcn_sched_barrier(0);
+    float fb = (float)(b * U);
+    asm volatile("" : "+v"(fb));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float fc = fb + (float)u;
+      const float du = rv[b][u].x - fc, dv = rv[b][u].y - fr;
+      const float d2 = fmaf(du, du, dv * dv);
+      const float t = d2 * rv[b][u].z;
+      const float r = __builtin_amdgcn_rsqf(fmaxf(t, 1e-37f));      // (see seg_bwd_row: m d = t r, m / d = m^2 r)
+      const float sc = fast_exp_neg(t * r);
+      const float g = c1[b][u] - c2[b][u] * __expf(sc);
+      const float kk = (-g * sc) * (rv[b][u].z * r);                 // (a masked slot read zeros: m^2 = 0, kk = 0)
+      const bool on = kk != 0.0f;
+      if (on && a[b][u] != cur) {
+        if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+        else seg_flush(acc, cur, sx, sy);
+        cur = a[b][u];
+        sx = 0.0f;
+        sy = 0.0f;
+      }
+      sx = fmaf(kk, du, sx);
+      sy = fmaf(kk, dv, sy);
+    }
+  }
+#undef SMPLR_SBL_LOAD
+#undef SMPLR_SBL_GATHER
+  if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
+  else seg_flush(acc, cur, sx, sy);
+}
+
 template <bool DET, bool LOSS>
 __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *__restrict__ dseg,
                                                       const short *__restrict__ arg,
                                                       const float4 *__restrict__ rec, int S, int VP, int W,
                                                       int P, float *__restrict__ dproj,
-                                                      float *__restrict__ part, int rows, LossIn li) {
+                                                      float *__restrict__ part, int rows, LossIn li, int pipe) {
   // SB_SLOTS x 2 accumulators: fp32 (32 KB), or 64-bit fixed point in the deterministic form (64 KB)
   extern __shared__ __attribute__((aligned(16))) float acc[];
   unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
@@ -1708,13 +1915,21 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
       for (int u = 0; u < SB_U; ++u) asm volatile("" : "+v"(pa[u]), "+v"(pg[u]));
       if (LOSS) {
         asm volatile("" : "+v"(warm));
-        if (nwin == 1 && fast)
+        if (nwin == 1 && fast && W == 48 && pipe)
+          seg_bwd_row_loss_pipe<4, 12, DET>(li, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg);
+        else if (nwin == 1 && fast && W == 64 && pipe)
+          seg_bwd_row_loss_pipe<4, 16, DET>(li, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg);
+        else if (nwin == 1 && fast)
           seg_bwd_row_loss<false, true, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
         else if (nwin == 1)
           seg_bwd_row_loss<false, false, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
         else
           seg_bwd_row_loss<true, false, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale, pa, pg);
-      } else if (nwin == 1 && fast)
+      } else if (nwin == 1 && fast && W == 48 && pipe)
+        seg_bwd_row_pipe<6, 8, DET>(dseg, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg);
+      else if (nwin == 1 && fast && W == 64 && pipe)
+        seg_bwd_row_pipe<4, 16, DET>(dseg, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg);
+      else if (nwin == 1 && fast)
         seg_bwd_row<false, true, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
       else if (nwin == 1)
         seg_bwd_row<false, false, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
@@ -2783,7 +2998,8 @@ static int seg_bwd_impl(const char *fn, const float *dseg, LossIn li, const int1
 #define SMPLR_SEGBWD_LAUNCH(DET_, LOSS_, lds_)                                                                       \
   hipLaunchKernelGGL((seg_bwd_kernel<DET_, LOSS_>), dim3(nsplit, B), dim3(32 * rows), lds_, st, dseg,                 \
                      reinterpret_cast<const short *>(arg), reinterpret_cast<const float4 *>(rec), S, VP, W, P, dproj, \
-                     reinterpret_cast<float *>(workspace), rows, li)
+                     reinterpret_cast<float *>(workspace), rows, li, pipe)
+  static const int pipe = getenv("SMPLR_SEGBWD_PIPE") ? atoi(getenv("SMPLR_SEGBWD_PIPE")) : 1;   // 0: the unpipelined row walk (A/B runs)
   if (deterministic) {
     const size_t lds = (size_t)SB_SLOTS * 2 * sizeof(unsigned long long);
     int rc = with_loss ? set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true, true>), lds)

@@ -88,6 +88,21 @@ class SMPLDecoder(nn.Module):
             raise RuntimeError("SMPLDecoder expects x of shape (B, %d)" % (self.num_cam + 82))
         c = self.constants(x.device)
         pt = ops.get_part_table(self.vs, x.device, c.V)
+        # gradient-free forward of the plain decoder (predict.py:99-118): ONE host call into the at::Tensor layer
+        # (torch.ops.smplraster.decoder_fwd, csrc/torch_ops.cpp) instead of the autograd node's ctypes calls - the same
+        # two launches, outputs bit for bit; at batch 1 the eager forward is host-bound and this is what it costs
+        if (labels is None and self.heads == ("seg",) and self.vs == 1 and self.streams == 1 and c.blend3_fwd is not None
+                and not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda and x.dtype == torch.float32
+                and x.shape[0] < ops.POSE_BLEND_SPLIT_B):
+            from . import torch_ops
+            if torch_ops.available():
+                o = torch_ops.load().decoder_fwd(x.contiguous(), c.as_list(), pt.part_pos, pt.part_off, self.img_wh,
+                                                 self.grid_wh, self.ref_compat, self.num_cam)
+                out = dict(J_transformed=o[4], seg=o[3])
+                for k, t in (("verts", o[0]), ("projects", o[1]), ("mask", o[2])):
+                    if k in self.outputs:
+                        out[k] = t
+                return out
         fused = self.loss is not None and labels is not None
         if labels is not None and self.loss is None:
             raise RuntimeError("labels were given but the decoder was built without loss=softmax_focal_loss(...)")

@@ -94,6 +94,14 @@ class SMPLConstants:
                   "smplr_blend3_pack")
         return self
 
+    def as_list(self):
+        """The constants in the order `torch.ops.smplraster.smpl_fwd / smpl_bwd / decoder_fwd` take them
+        (csrc/torch_ops.cpp): J_template, J_dirs, parents, v_template, blend3_fwd, blend3_bwd, lbs_weights, lbs_top4,
+        blend_t; absent optional ones as empty tensors."""
+        e = lambda t, dt=torch.float32: t if t is not None else torch.empty(0, dtype=dt, device=self.v_template.device)
+        return [self.J_template, self.J_dirs, self.parents, self.v_template, e(self.blend3_fwd, torch.uint8),
+                e(self.blend3_bwd, torch.uint8), self.lbs_weights, e(self.lbs_top4), self.blend_t]
+
     def fp32_gemm(self):
         """A view of the same constants that runs the blend GEMMs on the fp32 matrix cores."""
         import dataclasses

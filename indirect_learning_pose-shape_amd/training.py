@@ -21,6 +21,16 @@ from .focal_loss import softmax_focal_loss
 from .model import SMPLRegressor
 
 
+def configure_conv_backend():
+    """The encoder's convolutions run on stock torch (MIOpen).  With `cudnn.benchmark` off torch asks MIOpen for an
+    immediate-mode solution with a small fixed workspace, and for ENet's dilated / asymmetric convolutions MIOpen then
+    logs `GemmFwdRest ... IsEnoughWorkspace` warnings and falls back to a slower solver.  Find mode with torch's full
+    workspace picks a solver that fits; MIOPEN_FIND_MODE=FAST keeps the first-call search short (no tuning runs: fresh
+    boxes have no user database).  Call once, before the first convolution; an existing MIOPEN_FIND_MODE is respected."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    torch.backends.cudnn.benchmark = True
+
+
 class SegTrainer:
     """One optimiser step = `segs_model.fit` on one batch with the focal loss (train.py:207-242)."""
 
@@ -29,6 +39,8 @@ class SegTrainer:
                  with_silhouette=False, silh_wh=None, fused_loss=True):
         self.device = (torch.device(device) if device is not None
                        else torch.device("cuda", torch.cuda.current_device()))
+        if self.device.type == "cuda" and os.environ.get("SMPLR_CONV_BACKEND", "find") != "default":
+            configure_conv_backend()
         self.output_wh = output_wh
         self.smpl_model = SMPLRegressor(output_wh, encoder_architecture, use_IEF).to(self.device)
         self.loss_fn = softmax_focal_loss(gamma, weight_classes)      # softmax + focal loss, one HIP kernel
@@ -54,12 +66,17 @@ class SegTrainer:
                 bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True, broadcast_buffers=False)
         self.opt = torch.optim.Adam(self.smpl_model.parameters(), lr=lr)       # train.py:179
 
-    def step(self, images, labels, silh_labels=None):
+    def step(self, images, labels, silh_labels=None, _marks=None):
         """images (N,3,H,W) or (N,H,W,3); labels (N,W,W) integer class map or (N,W*W,32) one-hot, or None for the
         silhouette-only step of the alternating schedule (then silh_labels is required).
-        Returns the mean loss (a 0-d tensor; no host sync)."""
+        Returns the mean loss (a 0-d tensor; no host sync).  (`_marks`: see `step_timed`.)"""
+        mark = (lambda k: None) if _marks is None else _marks
+        mark("start")
         self.opt.zero_grad(set_to_none=True)
         param = self.net(images)
+        mark("encoder_fwd")
+        if _marks is not None and param.requires_grad:
+            param.register_hook(lambda g: (mark("decoder_bwd"), g)[1])     # fires between the decoder's and the encoder's backward
         if labels is None:
             # `silhouettes_model.fit` (train_stage2_silhouette.py:226-234, the 150 silhouette steps of :262-270):
             # the silhouette head alone - no mask, no binning, no 31-part rasteriser
@@ -77,9 +94,31 @@ class SegTrainer:
                 loss = self.loss_fn(labels, out["seg"]).mean()
             if self.with_silhouette and silh_labels is not None:  # train_stage2_silhouette.py:85-86,226-229
                 loss = loss + self.silh_loss_fn(silh_labels, out["silhouette"]).mean()
+        mark("decoder_fwd")
         loss.backward()
+        mark("backward")
         self.opt.step()
+        mark("optimizer")
         return loss.detach()
+
+    def step_timed(self, images, labels, silh_labels=None):
+        """One `step` with HIP events between its sections -> dict(encoder_ms, decoder_ms, optimizer_ms, total_ms):
+        encoder = regressor forward + its backward (under DDP that includes the all-reduce buckets it overlaps),
+        decoder = decoder + loss forward and backward (up to the gradient of the 86-vector), optimizer = zero_grad +
+        Adam.  Synchronises; a measurement aid for bench.py's train leg (train.py:179-242 is the step reproduced)."""
+        ev = {}
+
+        def mark(k):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.device))
+            ev[k] = e
+        self.step(images, labels, silh_labels, _marks=mark)
+        torch.cuda.synchronize(self.device)
+        dt = lambda a, b: ev[a].elapsed_time(ev[b])
+        dec_bwd_end = "decoder_bwd" if "decoder_bwd" in ev else "backward"
+        return {"encoder_ms": dt("start", "encoder_fwd") + dt(dec_bwd_end, "backward"),
+                "decoder_ms": dt("encoder_fwd", "decoder_fwd") + dt("decoder_fwd", dec_bwd_end),
+                "optimizer_ms": dt("backward", "optimizer"), "total_ms": dt("start", "optimizer")}
 
     @torch.no_grad()
     def monitor(self, images):

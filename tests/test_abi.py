@@ -129,3 +129,33 @@ def test_probing_a_stale_library_does_not_pin_its_mapping(tmp_path):
     assert _lib.library_build_id(str(tmp_path / "missing.so")) is None
     (tmp_path / "junk.so").write_bytes(b"not an ELF file")
     assert _lib.library_build_id(str(tmp_path / "junk.so")) is None
+
+
+def test_torch_library_registers_the_declared_ops():
+    """The at::Tensor layer (SURVEY.md 8(b): TORCH_LIBRARY(smplraster, ...) over the extern "C" launchers): every op
+    of `torch_ops.SCHEMAS` is registered with that schema, has a Meta kernel (output shapes without a device) and
+    refuses CPU tensors - no compute, runs without a GPU."""
+    import torch
+    from ilps_amd import torch_ops
+    ns = torch_ops.load()
+    for name, schema in torch_ops.SCHEMAS.items():
+        op = getattr(ns, name)
+        assert str(op.default._schema) == schema, (name, str(op.default._schema))
+    assert int(ns.abi_version()) == 6
+    m = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device="meta")
+    proj = m(2, 6890, 3)
+    assert ns.visibility(proj).shape == (2, 6890)
+    assert ns.project_fwd(m(2, 6890, 3), m(2, 86), 5).shape == (2, 1378, 3)
+    seg, arg, rec = ns.seg_fwd(proj, m(2, 6890), m(6879, dt=torch.int32), m(32, dt=torch.int32), 48)
+    assert seg.shape == (2, 48, 48, 32) and arg.shape == (2, 48, 48, 32) and arg.dtype == torch.int16 and rec.shape[2] == 4
+    assert ns.seg_bwd(m(2, 48, 48, 32), arg, rec, 6890, 31, 6879).shape == (2, 6890, 3)
+    silh, sarg = ns.silh_fwd(proj, 64)
+    assert silh.shape == (2, 64, 64, 2) and sarg.dtype == torch.int32
+    consts = [m(24, 3), m(24, 3, 10), m(24, dt=torch.int32), m(20670), m(64, dt=torch.uint8), m(64, dt=torch.uint8),
+              m(6890, 24), m(6890, 8), m(20670, 224)]
+    outs = ns.decoder_fwd(m(2, 86), consts, m(6879, dt=torch.int32), m(32, dt=torch.int32), 48)
+    assert [tuple(o.shape) for o in outs[:5]] == [(2, 6890, 3), (2, 6890, 3), (2, 6890), (2, 48, 48, 32), (2, 24, 3)]
+    assert ns.smpl_bwd(m(2, 6890, 3), None, None, m(2, 86), consts, m(2, 24, 9), m(2, 24, 3), m(2, 24, 12),
+                       m(2, 6890, 3)).shape == (2, 86)
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ns.visibility(torch.zeros(1, 10, 3))                 # a CPU tensor: no kernel registered for it

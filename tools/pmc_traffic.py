@@ -37,9 +37,9 @@ for k, cs in acc.items():
         e["l2_hit_rate"] = round(h / (h + m), 3)
     out["kernels"][k] = e
 seg = sum(v.get("hbm_bytes_per_launch", 0) for k, v in out["kernels"].items()
-          if k.startswith("seg_bin_kernel") or k.startswith("raster_fwd_kernel"))
+          if k.startswith("seg_bin_kernel") or k.startswith(("raster_fwd_kernel", "raster2_fwd_kernel")))
 out["seg_fwd_hbm_bytes_per_launch"] = seg
-out["seg_fwd_note"] = "seg_bin_kernel + raster_fwd_kernel (the two kernels of smplr_seg_fwd / smplr_vis_seg_fwd)"
+out["seg_fwd_note"] = "seg_bin_kernel + raster2_fwd_kernel (the two kernels of smplr_seg_fwd / smplr_vis_seg_fwd)"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import ilps_amd  # noqa: E402,F401

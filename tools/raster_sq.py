@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-KERNEL = "raster_fwd_kernel"
+KERNEL = "raster2_fwd_kernel"     # (round 4: the two-pixel kernel; rounds 1-3: raster_fwd_kernel)
 stats = sys.argv[1]
 issue_plain, issue_packed = (float(v) for v in sys.argv[2].split(","))
 us = None
@@ -27,8 +27,8 @@ for d in sys.argv[3:]:
 out = {"kernel": KERNEL, "kernel_us": us, "kernel_us_source": os.path.basename(stats), "simds": 1024, "clock_hz": 2.4e9,
        "clock_note": "nominal peak clock; the clock held under load is lower, so the fractions are lower bounds",
        "issue_cycles_plain": issue_plain, "issue_cycles_packed": issue_packed,
-       "issue_cycles_source": "tools/probes/valu_issue_probe (profiles/r02_valu_issue_probe.txt) at 4 waves per SIMD: v_fma_f32 "
-                              "(plain) and v_pk_fma_f32 / v_pk_add_f32 / v_min3_f32 (the pair loop's instructions)",
+       "issue_cycles_source": "tools/probes/valu_issue_probe (profiles/r04_valu_issue_probe.txt) at 8 waves per SIMD, the kernel's "
+                              "occupancy: v_fma_f32 (plain) and v_pk_fma_f32 / v_pk_add_f32 / v_min3_f32 (the pair loop's instructions)",
        "units": "SQ_INSTS_* = wave-instructions; SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* = quad-cycles (x4 = cycles), summed over the chip"}
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)
