@@ -22,11 +22,14 @@ from .model import SMPLRegressor
 
 
 def configure_conv_backend():
-    """The encoder's convolutions run on stock torch (MIOpen).  With `cudnn.benchmark` off torch asks MIOpen for an
-    immediate-mode solution with a small fixed workspace, and for ENet's dilated / asymmetric convolutions MIOpen then
-    logs `GemmFwdRest ... IsEnoughWorkspace` warnings and falls back to a slower solver.  Find mode with torch's full
-    workspace picks a solver that fits; MIOPEN_FIND_MODE=FAST keeps the first-call search short (no tuning runs: fresh
-    boxes have no user database).  Call once, before the first convolution; an existing MIOPEN_FIND_MODE is respected."""
+    """OPT-IN (`SMPLR_CONV_BACKEND=find`): MIOpen find mode with torch's full workspace (`cudnn.benchmark = True`,
+    MIOPEN_FIND_MODE=FAST unless set) for the encoder's stock-torch convolutions.  Not the default: on a fresh box (no
+    user database, no cached kernels) the first train step then spends MINUTES compiling and timing candidate solvers -
+    `tools/conv_backend_ab.sh` on an MI355X: default 28.9 s for the whole run of 8 steps at 26.07 ms per step and no
+    workspace warning; find mode silent for over 420 s (killed).  The `GemmFwdRest ... IsEnoughWorkspace` lines a
+    `bench.py` run prints (8 of them) come from the batch-1 predict leg's first convolution: immediate mode EVALUATES
+    that solver against the workspace torch sized for the solution it picked and logs that it does not fit; the step
+    above, at 128 images, prints none."""
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     torch.backends.cudnn.benchmark = True
 
@@ -39,7 +42,7 @@ class SegTrainer:
                  with_silhouette=False, silh_wh=None, fused_loss=True):
         self.device = (torch.device(device) if device is not None
                        else torch.device("cuda", torch.cuda.current_device()))
-        if self.device.type == "cuda" and os.environ.get("SMPLR_CONV_BACKEND", "find") != "default":
+        if self.device.type == "cuda" and os.environ.get("SMPLR_CONV_BACKEND", "default") == "find":
             configure_conv_backend()
         self.output_wh = output_wh
         self.smpl_model = SMPLRegressor(output_wh, encoder_architecture, use_IEF).to(self.device)

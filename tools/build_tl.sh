@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 PKG=indirect_learning_pose-shape_amd; OUT=${TMPDIR:-/tmp}/smplr_tl_build
 rm -rf "$OUT"; mkdir -p "$OUT/pkg/csrc" "$OUT/include"
 cp $PKG/csrc/*.hip $PKG/csrc/*.h $PKG/csrc/*.cpp $PKG/csrc/Makefile "$OUT/pkg/csrc/"; cp include/smplraster.h "$OUT/include/"
-make -C "$OUT/pkg/csrc" LIB=../lib_tl.so CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -DSMPLR_TL" > "$OUT/build.log" 2>&1 || { tail -20 "$OUT/build.log"; exit 1; }
+make -C "$OUT/pkg/csrc" LIB=../lib_tl.so ../lib_tl.so CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function -DSMPLR_TL" > "$OUT/build.log" 2>&1 || { tail -20 "$OUT/build.log"; exit 1; }
 cp "$OUT/pkg/lib_tl.so" $PKG/lib_tl.so
 echo "built $PKG/lib_tl.so"
