@@ -144,8 +144,11 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   unsigned long long *zbuf = reinterpret_cast<unsigned long long *>(s_cnt + ((npix + 1) & ~1));
   unsigned int *vis = reinterpret_cast<unsigned int *>(zbuf + cells);
   float *sU = reinterpret_cast<float *>(vis + words), *sV = sU + VP;
-  // vertex -> record slot (for the backward's gather by vertex), staged here and copied out at the end
-  short *sSlot = reinterpret_cast<short *>(sU + (STAGE ? 2 * VP : 0));
+  // vertex -> record slot (for the backward's gather by vertex).  Round 4: written straight to global memory - -1
+  // everywhere up front (coalesced, under the first requests), a record's slot by the placement (a 2-B store per
+  // record, nothing waits for it; the barriers in between order the two stores to one address) - instead of a map
+  // staged in 13.8 KB of LDS and copied out behind one more barrier: 2.8 k of the kernel's 48 k clocks.
+  short *vsl = vslot ? vslot + (size_t)n * VP : nullptr;
 
   // ---- every global operand of the block, requested up front
   const int ipt = (K + BIN_T - 1) / BIN_T;      // <= IPT_MAX (checked by the launcher)
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   if (tid == 0) { s_nonunit = 0; s_any_empty = 0; }
   for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
   if (vslot)                                                  // block-uniform
-    for (int i = tid; i < VP; i += BIN_T) sSlot[i] = -1;
+    for (int i = tid; i < VP; i += BIN_T) vsl[i] = -1;
   if (VIS) {
     for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
     for (int i = tid; i < words; i += BIN_T) vis[i] = 0u;
@@ -377,13 +380,13 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       if (s.cls == 1) {
         const int slot = s_gpad[p] + (run - s_gstart[p]);
         Gn[slot] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
-        if (vslot) sSlot[s.pos] = (short)slot;
+        if (vslot) vsl[s.pos] = (short)slot;
         ++run;
       } else if (s.cls == 2) {
         const int dst = atomicAdd(&s_cnt[s.pix], 1);
         lrecn[dst] = make_uint2(__float_as_uint(s.x), (unsigned)p);
         Gn[s_gpad[P] + dst] = make_float4(s.u, s.v, s.m * s.m, __int_as_float(s.pos));
-        if (vslot) sSlot[s.pos] = (short)(s_gpad[P] + dst);
+        if (vslot) vsl[s.pos] = (short)(s_gpad[P] + dst);
       }
     }
   }
@@ -399,12 +402,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
       Gn[i] = make_float4(INFINITY, INFINITY, 1.0f, __int_as_float(-1));
   }
   SMPLR_TL_STAMP(16);
-  if (vslot) {                                                // block-uniform
-    __syncthreads();
-    SMPLR_TL_STAMP(17);
-    short *vo = vslot + (size_t)n * VP;
-    for (int i = tid; i < VP; i += BIN_T) vo[i] = sSlot[i];
-  }
+  SMPLR_TL_STAMP(17);
   SMPLR_TL_STAMP(18);
 }
 
@@ -2705,7 +2703,8 @@ static BinLds bin_lds(int VP, int W, int grid_wh /* 0: mask not fused */, bool w
   BinLds b;
   b.base = (size_t)((W * W + 1) & ~1) * sizeof(int);
   if (grid_wh > 0) b.base += (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
-  b.slot = with_vslot ? ((size_t)VP * 2 + 15) / 16 * 16 : 0;
+  (void)with_vslot;
+  b.slot = 0;                                  // (rounds 1-3 staged the vertex -> slot map here; it goes straight to memory now)
   b.stage = b.base + b.slot + (size_t)VP * 8 <= 150 * 1024;
   b.total = b.base + b.slot + (b.stage ? (size_t)VP * 8 : 0);
   return b;
