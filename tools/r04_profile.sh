@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (one gpurun call): round 4's reference measurements -> gpurun_out/$TAG/
-#   bash tools/r04_profile.sh TAG [quick|traffic]
+#   bash tools/r04_profile.sh TAG [quick|traffic|main|variants]   ("main" then "variants" under the SAME tag = everything, in
+#   two gpurun calls of < 20 minutes each; files merge in gpurun_out/TAG)
 # default bench line, rocprofv3 kernel traces (default command + eager, one dispatch per kernel per step), PMC passes
 # (SQ x2, FETCH, WRITE, TCC - each set in its own pass, kernel trace off) of the eager default step, and FETCH / WRITE
 # passes + an eager kernel trace of the step VARIANTS (bench.py --step seg_only | fused_loss | unfused_loss | both_heads |
@@ -11,6 +12,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 export TMPDIR=/tmp
+if [ "$MODE" = variants ]; then SKIP_MAIN=1; fi
+if [ -z "$SKIP_MAIN" ]; then
 if [ "$MODE" != traffic ]; then
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-200 $O/bench.json
 fi
@@ -30,7 +33,10 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   if [ "$MODE" = traffic ] && [ $i -le 2 ]; then continue; fi
   (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_step_$i -- python3 $R/bench.py --steps 3 --warmup 2 --min-warmup 20 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/pmc_step_$i.log 2>&1; echo "pmc step pass $i rc=$?") || exit 1
 done
-for V in seg_only fused_loss unfused_loss both_heads silhouette_only; do
+fi   # SKIP_MAIN
+VARIANTS="seg_only fused_loss unfused_loss both_heads silhouette_only"
+[ "$MODE" = main ] && VARIANTS=""
+for V in $VARIANTS; do
   (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$V -- python3 $R/bench.py --step $V --steps 20 --warmup 5 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/rocprof_$V.log 2>&1; echo "rocprof($V) rc=$?") || exit 1
   cp $(ls $O/prof_$V/*/*_kernel_stats.csv | head -1) $O/${V}_kernel_stats.csv 2>/dev/null
   j=0
@@ -39,6 +45,7 @@ for V in seg_only fused_loss unfused_loss both_heads silhouette_only; do
     (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $O/pmc_${V}_$j -- python3 $R/bench.py --step $V --steps 3 --warmup 2 --min-warmup 20 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg > $O/pmc_${V}_$j.log 2>&1; echo "pmc $V pass $j rc=$?") || exit 1
   done
 done
+[ "$MODE" = variants ] && { find $O -name "*.db" -delete 2>/dev/null; du -sh $O; exit 0; }
 # the reference's other shipped sizes: W = 64 (train.py:320-321, predict.py:129-136) and
 # vertex_sampling 5 / 2 at W = 48 (profiling_renderer.py:26) - eager kernel trace of the same step
 for CFG in "w64 --wh 64" "vs5 --vertex-sampling 5" "vs2 --vertex-sampling 2"; do
