@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/smplraster.h"
 
 namespace smplr {
@@ -110,9 +111,13 @@ constexpr int SB_ROWS_BIG = 24;  // ... and while that gives every CU one to fou
                                  // (B = 128: seg_bwd -1.0 us, skin_bwd -0.4; at B = 32 it would cost 4 us)
 inline int seg_bwd_rows(int B, int W) {
   // seg_bwd + skin_bwd at W = 48, 8 against 24 rows: B = 128 42.4 / 41.0 us, 256: 81.9 / 78.3, 512: 153.3 / 156.9,
-  // 2048: 578 / 601 - the tall blocks pay off between one and four blocks per CU
+  // 2048: 578 / 601 (round 3's kernels) - the tall blocks pay off from one block per CU on
   const long long n = (long long)B * ((W + SB_ROWS_BIG - 1) / SB_ROWS_BIG);
-  return (n >= 256 && n < 1024) ? SB_ROWS_BIG : SB_ROWS;
+  // (round 4, with the pipelined row walk: tall blocks at every batch from there on - B = 2 048: seg_bwd 260 -> 289 us,
+  // skin_bwd 261 -> 233 (two partials to gather per vertex instead of six), step 1.442 -> 1.432 ms; B = 512: 0.3897 -> 0.3871;
+  // SMPLR_SEGBWD_TALL_TO=1024 restores round 3's upper end)
+  static const long long tall_to = getenv("SMPLR_SEGBWD_TALL_TO") ? atoll(getenv("SMPLR_SEGBWD_TALL_TO")) : (1ll << 40);
+  return (n >= 256 && n < tall_to) ? SB_ROWS_BIG : SB_ROWS;
 }
 struct SegGrad { const float *part; const int16_t *vslot; int nsplit; };
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
