@@ -1088,7 +1088,7 @@ template <bool LOSS, int NG2>
 __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS void raster2_fwd_kernel(
     const float4 *__restrict__ G, const int *__restrict__ goff, const int *__restrict__ lstart,
     const uint2 *__restrict__ lrec, int P, int K, int S, int W, int B, int ntiles, float *__restrict__ seg,
-    short *__restrict__ arg, unsigned wmagic, LossOut lo, int stagger_blocks, int stagger_cycles) {
+    short *__restrict__ arg, unsigned wmagic, LossOut lo) {
   constexpr int NT = PLN * NG2;          // threads
   __shared__ float sS[RTS * SLD];
   __shared__ short sA[RTS * ALD];
@@ -1115,6 +1115,23 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   const float4 *Gn = G + (size_t)n * S;
   const int *goffn = goff + (size_t)n * (P + 2);
   const int C = P + 1;
+  // (the records and offsets first: the table build and the block's first barrier wait for them, the items' list
+  // bounds are not needed before the write-out)
+  const uint2 *lrecn = lrec + (size_t)n * K;
+  const int lbase = goffn[P];
+  const bool unit_m = goffn[P + 1] == 0;                 // every far-reaching weight is 1 (block-uniform)
+  const int goffv = goffn[min(tid, P)];                  // (stored to sOff below, behind the items' requests)
+  // table rows per group at this block: the smallest instantiation that holds its image rows
+  const int Rb = nrows <= 4 ? 5 : nrows <= 6 ? 7 : nrows <= 8 ? 9 : 11;
+  const int trec = (ARENA / (4 * Rb)) * 4;
+  // thread i asks for record i (and i + NT ... while the arena could hold it) before the list length is known: the
+  // records share the block's first round trip to memory; slots beyond the list hold stale bytes nobody reads
+  constexpr int NH = (trec_of(5) + NT - 1) / NT;
+  float4 rcs[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+    rcs[h] = (h == 0 || tid + h * NT < trec) ? Gn[min(tid + h * NT, S - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool tbl = unit_m && nrows <= R2_MAX - 1 && lbase <= trec;     // block-uniform
   // merge / write-out items: item e = it * NT + tid is tile pixel e / 4 (= 2 x pair-lane + row of the pair); its lane
   // sub4 = e % 4 takes the channel chunks sub4 and sub4 + 4 (channels 4 sub4 .. and 16 + 4 sub4 ..): four lanes per
   // pixel, ONE item per thread at 1 024 threads - the per-item fixed cost (pixel decode, list bounds, addresses) of
@@ -1142,32 +1159,7 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
       lab[it] = lo.labels[(size_t)n * npix + (unsigned)((W - 1 - rr) * W + ci)];
     }
   }
-  const uint2 *lrecn = lrec + (size_t)n * K;
-  const int lbase = goffn[P];
-  const bool unit_m = goffn[P + 1] == 0;                 // every far-reaching weight is 1 (block-uniform)
-  if (tid <= P) sOff[tid] = goffn[tid];
-  // table rows per group at this block: the smallest instantiation that holds its image rows
-  const int Rb = nrows <= 4 ? 5 : nrows <= 6 ? 7 : nrows <= 8 ? 9 : 11;
-  const int trec = (ARENA / (4 * Rb)) * 4;
-  // thread i asks for record i (and i + NT ... while the arena could hold it) before the list length is known: the
-  // records share the block's first round trip to memory; slots beyond the list hold stale bytes nobody reads
-  constexpr int NH = (trec_of(5) + NT - 1) / NT;
-  float4 rcs[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h)
-    rcs[h] = (h == 0 || tid + h * NT < trec) ? Gn[min(tid + h * NT, S - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool tbl = unit_m && nrows <= R2_MAX - 1 && lbase <= trec;     // block-uniform
-  // Stagger (speed only, no effect on results): two blocks share a CU, start together and - all blocks costing the
-  // same - stay in step for the whole launch: both in their vector-bound scan, then both in their latency-bound
-  // prologue / barrier / write-out, the vector unit idle.  The second block of a CU's first pair (it sits in wave
-  // slots 4-7 of each SIMD, HW_ID[3:0]: tools/probes/raster_slots.py) waits here, behind its requests, for about half
-  // a block's lifetime; every later block starts when a slot frees, i.e. already out of step with its neighbour.
-  if (bid < stagger_blocks) {
-    if ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 15u) >= 4u) {      // HW_REG_HW_ID, bits 3:0 = wave slot
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger_cycles) __builtin_amdgcn_s_sleep(8);
-    }
-  }
+  if (tid <= P) sOff[tid] = goffv;
   SMPLR_TL_STAMP(1);
   if (tbl) {
     float *tab = reinterpret_cast<float *>(sTab);
@@ -2814,18 +2806,6 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
     const int *lsp = reinterpret_cast<const int *>(base + ws.lstart_off);
     const uint2 *lrp = reinterpret_cast<const uint2 *>(base + ws.lrec_off);
     short *argp = reinterpret_cast<short *>(arg);
-    // stagger: the first 2 x CUs blocks are the launch's first round (two 16-wave blocks per CU); off for grids that
-    // do not fill it
-    static const int stag_env = getenv("SMPLR_RASTER_STAGGER") ? atoi(getenv("SMPLR_RASTER_STAGGER")) : 0;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      hipDeviceProp_t pr;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n_cu = pr.multiProcessorCount;
-      else n_cu = 256;
-    }
-    const int stag_cyc = stag_env;
-    const int stag_blocks = (stag_cyc > 0 && grid2 >= 2 * n_cu) ? 2 * n_cu : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (kernel_ms) {
       SMPLR_HIP(hipEventCreate(&e0));
@@ -2835,10 +2815,10 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
   {                                                                                                                 \
     if (kernel_ms)                                                                                                  \
       hipExtLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_>), dim3(grid2), dim3(PLN * NG_), 0, as_stream(stream), e0, \
-                            e1, 0, Gp, goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo, stag_blocks, stag_cyc); \
+                            e1, 0, Gp, goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo);                         \
     else                                                                                                            \
       hipLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_>), dim3(grid2), dim3(PLN * NG_), 0, as_stream(stream), Gp,  \
-                         goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo, stag_blocks, stag_cyc);            \
+                         goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo);                                   \
   }
     if (with_loss) { if (ng2 == 4) SMPLR_RASTER2_LAUNCH(true, 4) else SMPLR_RASTER2_LAUNCH(true, 8) }
     else { if (ng2 == 4) SMPLR_RASTER2_LAUNCH(false, 4) else SMPLR_RASTER2_LAUNCH(false, 8) }
