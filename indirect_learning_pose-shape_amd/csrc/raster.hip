@@ -35,6 +35,7 @@
 #include "common.h"
 
 namespace smplr {
+__host__ __device__ constexpr int goff_stride(int P) { return P + 2 + 32; }   // ints per mesh in `goff`
 
 constexpr int CH = SMPLR_CHUNK;      // 8: silhouette list padding
 static int set_lds_attr(const void *fn, size_t lds);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   }
   SMPLR_TL_STAMP(7);
   float4 *Gn = G + (size_t)n * S;
-  int *goffn = goff + (size_t)n * (P + 2);
+  int *goffn = goff + (size_t)n * goff_stride(P);
   int *lstartn = lstart + (size_t)n * (npix + 1);
   uint2 *lrecn = lrec + (size_t)n * K;
 
@@ -340,28 +341,39 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   SMPLR_TL_STAMP(11);
   __syncthreads();
   SMPLR_TL_STAMP(12);
-  if (tid < 64) {
+  if (tid < 128) {
     // global prefix at each part's first slot: the owning thread's base + its global flags below that slot
     // (empty parts share a slot; parts that start at K take the total); then the padded part offsets (P <= 31)
+    const int l = tid & 63;
     int gs = gtotal;
-    const int kk = s_poff[tid <= P ? tid : P];
-    if (tid < P && kk < K) {
+    const int kk = s_poff[l <= P ? l : P];
+    if (l < P && kk < K) {
       const int t = kk / ipt, j = kk - t * ipt;
       const int w = s_gb[t];
       gs = (w & 0xffff) + __popc(((unsigned)w >> 16) & ((1u << j) - 1u));
     }
     const int gnext = __shfl_down(gs, 1, 64);
-    const int cnt = (tid < P) ? (gnext - gs + GP - 1) / GP * GP : 0;
-    int inc = cnt;
+    const int cnt = (l < P) ? (gnext - gs + GP - 1) / GP * GP : 0;
+    if (tid < 64) {
+      int inc = cnt;
 #pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      const int t = __shfl_up(inc, o, 64);
-      if (tid >= o) inc += t;
-    }
-    if (tid <= P) {
-      s_gstart[tid] = gs;
-      s_gpad[tid] = inc - cnt;                 // tid == P: cnt = 0, inc = total
-      goffn[tid] = inc - cnt;
+      for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (tid >= o) inc += t;
+      }
+      if (tid <= P) {
+        s_gstart[tid] = gs;
+        s_gpad[tid] = inc - cnt;               // tid == P: cnt = 0, inc = total
+        goffn[tid] = inc - cnt;
+      }
+    } else {
+      // the block's second wave, beside the prefix: the parts in order of record count (largest first, ties by part
+      // number) for the rasteriser, whose waves take them from this list as they become free (raster2_fwd_kernel)
+      const int key = l < P ? ((cnt << 5) | (31 - l)) : -1;                    // distinct keys; cnt < 2^16
+      int rank = 0;
+#pragma unroll
+      for (int q = 0; q < 31; ++q) rank += (__builtin_amdgcn_readlane(key, q) > key) ? 1 : 0;
+      if (l < P) goffn[P + 2 + rank] = l;
     }
   }
   SMPLR_TL_STAMP(13);
@@ -683,7 +695,7 @@ __global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel
   const int r = (int)(((unsigned)qc * wmagic) >> 24), c = qc - r * W;
   const float fc = (float)c, fr = (float)r;
   const float4 *Gn = G + (size_t)n * S;
-  const int *goffn = goff + (size_t)n * (P + 2);
+  const int *goffn = goff + (size_t)n * goff_stride(P);
   const int C = P + 1;
   // everything the block needs from global memory is requested up front (one round trip): the
   // pixel's local-record range, the list length, the unit-weight flag, the part offsets (-> LDS)
@@ -1001,9 +1013,20 @@ __global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel
 // Keys, tie rules, merge and write-out are raster_fwd_kernel's, expression for expression: outputs are bit-identical
 // (tools/probes/seg_hash.py).  Blocks whose tables do not fit (list longer than TREC(R), a weight other than 1, more
 // than 10 image rows under the block) walk the global record list with scalar loads - exact, slow, rare.
-constexpr int PLN = 128;                 // pair-lanes per block: 2 x 64
+constexpr int PLN = 128;                 // pair-lanes per block: 2 x 64 (the large-batch shape)
+// The block shape by batch: 1 = 128 pair-lanes x 8 part ranges (two blocks per CU), 2 = 64 x 10 (three per CU).  The
+// small blocks cost a second table build per 256 pixels and pay while the large ones would leave CUs idle or
+// half-filled: up to about two rounds of the large shape (512 blocks on 256 CUs at a time).
+__host__ inline int raster2_shape(int B, int W) {
+  const long long nl = (long long)((W + 1) / 2) * W, blocks1 = (long long)B * ((nl + PLN - 1) / PLN);
+  return blocks1 <= 900 ? 2 : 1;          // (W = 48: up to 100 meshes; step A/B at B = 96: -1.2 %, at 112: +1.5 %)
+}
+#ifndef SMPLR_R2_STATIC
+#define SMPLR_R2_STATIC 1
+#endif
+constexpr int R2_STATIC = SMPLR_R2_STATIC;   // parts a wave takes by the static deal before it draws from the shared list (1..4)
 constexpr int R2_MAX = 11;               // table rows + 1 of the largest instantiation
-__host__ __device__ constexpr int trec_of(int R) { return (ARENA / (4 * R)) * 4; }   // records the arena holds at R rows per group
+__host__ __device__ constexpr int trec_of(int AR, int R) { return (AR / (4 * R)) * 4; }   // records an arena of AR floats holds at R rows per group
 
 template <int R>
 __device__ __forceinline__ void scan2_body(const char *tb, unsigned vu, unsigned vt, int off, int gid, f32x2 fc2,
@@ -1037,14 +1060,22 @@ __device__ __forceinline__ int rescan2(const char *tb, int g, unsigned va, f32x2
   return (best < INFINITY) ? w : -1;
 }
 
-// A wave's parts [ps, pe) for its 64 pair-lanes, unit weights, table mode.  offv: the part offsets, one per lane.
-template <int R>
-__device__ __forceinline__ void scan2_parts(const char *tb, int offv, int ps, int pe, unsigned va, f32x2 fc2,
-                                            float *myS, short *myA) {
+// A wave's parts for its 64 pair-lanes, unit weights, table mode.  offv: the part offsets, one per lane; ordv: the parts
+// by size, one per lane.  Wave g of NG takes the list entries g, 2 NG - 1 - g, ... (boustrophedon) for its first
+// R2_STATIC parts and the rest from the counter the block's waves of this pixel half share (asked for before the part
+// in hand is scanned: the answer is there when it is needed).
+template <int R, int NG>
+__device__ __forceinline__ int scan2_parts(const char *tb, int offv, int ordv, int *ctr, int g, int P, bool lane0,
+                                           unsigned va, f32x2 fc2, float *myS, short *myA) {
   constexpr int GB = R * 16;             // bytes per group
-  int beg = __builtin_amdgcn_readlane(offv, ps);
-  for (int p = ps; p < pe; ++p) {
-    const int end = __builtin_amdgcn_readlane(offv, p + 1);
+  int done = 1, r = g;
+  while (r < P) {
+    int rn = 0;
+    if (done >= R2_STATIC) {
+      if (lane0) rn = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const int p = __builtin_amdgcn_readlane(ordv, r);
+    const int beg = __builtin_amdgcn_readlane(offv, p), end = __builtin_amdgcn_readlane(offv, p + 1);
     float bestA = INFINITY, bestB = INFINITY;
     int sA_ = -1, sB_ = -1;
     if (beg < end) {
@@ -1080,53 +1111,61 @@ __device__ __forceinline__ void scan2_parts(const char *tb, int offv, int ps, in
     myS[SLD + p] = fast_exp_neg(fast_sqrt(bestB));
     myA[p] = (short)sA_;
     myA[ALD + p] = (short)sB_;
-    beg = end;
+    const int sn = (done & 1) ? (done + 1) * NG - 1 - g : done * NG + g;       // the wave's done-th entry of the static deal
+    r = (done < R2_STATIC) ? sn : __builtin_amdgcn_readfirstlane(rn);
+    ++done;
   }
+  return done - 1;
 }
 
-template <bool LOSS, int NG2>
-__global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS void raster2_fwd_kernel(
+template <bool LOSS, int NG2, int PL>
+__global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SGPRS void raster2_fwd_kernel(
     const float4 *__restrict__ G, const int *__restrict__ goff, const int *__restrict__ lstart,
     const uint2 *__restrict__ lrec, int P, int K, int S, int W, int B, int ntiles, float *__restrict__ seg,
     short *__restrict__ arg, unsigned wmagic, LossOut lo) {
-  constexpr int NT = PLN * NG2;          // threads
-  __shared__ float sS[RTS * SLD];
-  __shared__ short sA[RTS * ALD];
-  __shared__ f32x4 sTab[ARENA / 4];      // [group][row 0 = u | rows 1.. = (v - row)^2][4 records]
-  __shared__ int sOff[40];
+  constexpr int NT = PL * NG2;           // threads
+  constexpr int TS = 2 * PL;             // pixels of the block's tile
+  constexpr int PW = PL / 64;            // waves per part range (64 pair-lanes each)
+  __shared__ float sS[TS * SLD];
+  __shared__ short sA[TS * ALD];
+  constexpr int AR = PL == 64 ? 6144 : ARENA;            // floats of the table's arena (three 64-lane blocks per CU: 51 KB each)
+  __shared__ f32x4 sTab[AR / 4];         // [group][row 0 = u | rows 1.. = (v - row)^2][4 records]
+  __shared__ int sCtr[PW];               // next free entry of the part list, per 64 pair-lanes
   const int bid = blockIdx.x;
   const int xcd = bid & 7, idx = bid >> 3;
   const int n = (idx / ntiles) * 8 + xcd, tile = idx % ntiles;
   if (n >= B) return;                                    // block-uniform
   const int tid = threadIdx.x, lane = tid & 63;
+  if (tid < PW) sCtr[tid] = R2_STATIC * NG2;
   SMPLR_TL_WAVE(g_tl_raster, 16, n * ntiles + tile, TL_RASTER_WG)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave >> 1, pw = wave & 1;                // part range, 64-lane half of the block
+  const int g = wave / PW, pw = wave % PW;               // part range, 64-lane slice of the block
   const int npix = W * W;
   const int nq = (W + 1) >> 1, nl = nq * W;              // row pairs, pair-lanes of an image
   // this lane's pixel pair: pair-lane L = Q W + c -> pixels (2Q, c), (2Q + 1, c)
   const int Lb = pw * 64 + lane;
-  const int L = min(tile * PLN + Lb, nl - 1);
+  const int L = min(tile * PL + Lb, nl - 1);
   const int Q = (int)(((unsigned)L * wmagic) >> 24), c = L - Q * W;     // L < W^2 <= 25600: exact (see raster_fwd_kernel)
   // rows under the block: pairs Qf .. Ql
-  const int Qf = (int)(((unsigned)min(tile * PLN, nl - 1) * wmagic) >> 24);
-  const int Ql = (int)(((unsigned)min(tile * PLN + PLN - 1, nl - 1) * wmagic) >> 24);
+  const int Qf = (int)(((unsigned)min(tile * PL, nl - 1) * wmagic) >> 24);
+  const int Ql = (int)(((unsigned)min(tile * PL + PL - 1, nl - 1) * wmagic) >> 24);
   const int row0 = 2 * Qf, nrows = 2 * (Ql - Qf + 1);    // (an odd W's last pair has a phantom row W: built, never written out)
   const float4 *Gn = G + (size_t)n * S;
-  const int *goffn = goff + (size_t)n * (P + 2);
+  const int *goffn = goff + (size_t)n * goff_stride(P);
   const int C = P + 1;
   // (the records and offsets first: the table build and the block's first barrier wait for them, the items' list
   // bounds are not needed before the write-out)
   const uint2 *lrecn = lrec + (size_t)n * K;
   const int lbase = goffn[P];
   const bool unit_m = goffn[P + 1] == 0;                 // every far-reaching weight is 1 (block-uniform)
-  const int goffv = goffn[min(tid, P)];                  // (stored to sOff below, behind the items' requests)
+  const int goffv = goffn[min(lane, P)];                 // the part offsets, one per lane, in every wave
+  const int ordv = goffn[P + 2 + (lane & 31)];           // ... and the parts by size (seg_bin_kernel)
   // table rows per group at this block: the smallest instantiation that holds its image rows
   const int Rb = nrows <= 4 ? 5 : nrows <= 6 ? 7 : nrows <= 8 ? 9 : 11;
-  const int trec = (ARENA / (4 * Rb)) * 4;
+  const int trec = trec_of(AR, Rb);
   // thread i asks for record i (and i + NT ... while the arena could hold it) before the list length is known: the
   // records share the block's first round trip to memory; slots beyond the list hold stale bytes nobody reads
-  constexpr int NH = (trec_of(5) + NT - 1) / NT;
+  constexpr int NH = (trec_of(AR, 5) + NT - 1) / NT;
   float4 rcs[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
@@ -1136,18 +1175,18 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   // sub4 = e % 4 takes the channel chunks sub4 and sub4 + 4 (channels 4 sub4 .. and 16 + 4 sub4 ..): four lanes per
   // pixel, ONE item per thread at 1 024 threads - the per-item fixed cost (pixel decode, list bounds, addresses) of
   // raster_fwd_kernel's 8-lanes-per-pixel form once per 8 channels instead of once per 4
-  constexpr int NIT = RTS * 4 / NT;
+  constexpr int NIT = (TS * 4 + NT - 1) / NT;
   const int sub = tid & 3;
   int l0a[NIT], l1a[NIT], qqa[NIT];
   int lab[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int pl = (it * NT + tid) >> 2;
-    const int Li = tile * PLN + (pl >> 1);
+    const int Li = tile * PL + (pl >> 1);
     const int Lc = min(Li, nl - 1);
     const int Qi = (int)(((unsigned)Lc * wmagic) >> 24), ci = Lc - Qi * W;
     const int ri = 2 * Qi + (pl & 1);
-    const bool ok = Li < nl && ri < W;
+    const bool ok = Li < nl && ri < W && (TS * 4 % NT == 0 || pl < TS);       // (threads past the tile's items: none)
     const int qq = ok ? ri * W + ci : -1;                // the item's pixel (row-major, unflipped), -1: none
     qqa[it] = qq;
     const int *lp = lstart + (size_t)n * (npix + 1) + (ok ? qq : 0);
@@ -1159,7 +1198,6 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
       lab[it] = lo.labels[(size_t)n * npix + (unsigned)((W - 1 - rr) * W + ci)];
     }
   }
-  if (tid <= P) sOff[tid] = goffv;
   SMPLR_TL_STAMP(1);
   if (tbl) {
     float *tab = reinterpret_cast<float *>(sTab);
@@ -1197,35 +1235,28 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   float *myS = &sS[(2 * Lb) * SLD + 1];                  // indexed by part (channel = part + 1); second pixel at + SLD
   short *myA = &sA[(2 * Lb) * ALD + 1];
 
-  // this wave's parts [ps, pe): as raster_fwd_kernel cuts them (midpoint of the part's span in the cost prefix)
-  int ps, pe;
+  // Which parts this wave scans: the block's NG2 waves of a pixel half share a list of the parts, largest first
+  // (seg_bin_kernel sorts them); wave g starts on entry g and takes the next free entry whenever it finishes one - list
+  // scheduling, longest first.  (Round 3 cut the part list into NG2 contiguous runs of equal estimated cost: with 31
+  // parts on 8 ranges the longest range ran 1.32 x the mean and the block waited for it at the barrier.)  Which wave
+  // evaluates a (pixel, part) does not enter the result.
+  int ndone = 0;
+  (void)ndone;                                           // (timeline builds record it)
   {
-    const int lp = lane < P ? lane : 0;                  // P <= 31 parts
-    const int mid2 = sOff[lp] + sOff[lp + 1] + PART_COST * (2 * lp + 1);     // 2 x midpoint
-    const int total = __builtin_amdgcn_readfirstlane(sOff[P]) + PART_COST * P;
-    const unsigned long long b0 = __ballot(lane < P && NG2 / 2 * mid2 < total * g);          // mid2 / 2 < total g / NG2
-    const unsigned long long b1 = __ballot(lane < P && NG2 / 2 * mid2 < total * (g + 1));
-    ps = (g == 0) ? 0 : __popcll(b0);
-    pe = (g == NG2 - 1) ? P : __popcll(b1);
-  }
-#ifdef SMPLR_TL
-  const int ps0 = ps, pe0 = pe;
-#endif
-  {
-    const int offv = sOff[lane <= P ? lane : P];
+    const int offv = goffv;
     const char *tb = reinterpret_cast<const char *>(sTab);
     const unsigned va = (unsigned)(1 + 2 * (Q - Qf)) * 16u;      // byte offset of the upper pixel's table row in a group
     if (tbl) {
-      if (Rb == 5) scan2_parts<5>(tb, offv, ps, pe, va, fc2, myS, myA);
-      else if (Rb == 7) scan2_parts<7>(tb, offv, ps, pe, va, fc2, myS, myA);
-      else if (Rb == 9) scan2_parts<9>(tb, offv, ps, pe, va, fc2, myS, myA);
-      else scan2_parts<11>(tb, offv, ps, pe, va, fc2, myS, myA);
+      if (Rb == 5) ndone = scan2_parts<5, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
+      else if (Rb == 7) ndone = scan2_parts<7, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
+      else if (Rb == 9) ndone = scan2_parts<9, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
+      else ndone = scan2_parts<11, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
     } else {
       // the global record list by scalar loads, one record at a time (strict '<': the first arg-min in list order)
       const float fr0 = (float)(2 * Q), fr1 = fr0 + 1.0f;
-      int beg = __builtin_amdgcn_readlane(offv, ps);
-      for (int p = ps; p < pe; ++p) {
-        const int end = __builtin_amdgcn_readlane(offv, p + 1);
+      for (int r = g; r < P; r += NG2) {                   // (no balancing here)
+        const int p = __builtin_amdgcn_readlane(ordv, r);
+        const int beg = __builtin_amdgcn_readlane(offv, p), end = __builtin_amdgcn_readlane(offv, p + 1);
         float bestA = INFINITY, bestB = INFINITY;
         int sA_ = -1, sB_ = -1;
         for (int k = beg; k < end; ++k) {
@@ -1241,7 +1272,6 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
         myS[SLD + p] = (bestB < INFINITY) ? fast_exp_neg(fast_sqrt(bestB)) : 0.0f;
         myA[p] = (short)sA_;
         myA[ALD + p] = (short)sB_;
-        beg = end;
       }
     }
   }
@@ -1269,7 +1299,7 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int e = it * NT + tid;
-    const int pl = e >> 2, cA = sub * 4, cB = 16 + sub * 4;
+    const int pl = (TS * 4 % NT == 0) ? (e >> 2) : min(e >> 2, TS - 1), cA = sub * 4, cB = 16 + sub * 4;
     {
       int *rowS = reinterpret_cast<int *>(&sS[pl * SLD + 1]);
       short *rowA = &sA[pl * ALD + 1];
@@ -1386,7 +1416,7 @@ __global__ __launch_bounds__(PLN * NG2, (NG2 == 8 ? 8 : 4)) SMPLR_RASTER_SGPRS v
   }
   SMPLR_TL_STAMP(6);
 #ifdef SMPLR_TL
-  if (tl__) { tl__[7] = (unsigned)(pe0 - ps0); tl__[8] = (unsigned)g; }
+  if (tl__) { tl__[7] = (unsigned)ndone; tl__[8] = (unsigned)g; }
 #endif
 }
 
@@ -2709,7 +2739,7 @@ static SegWs seg_ws_layout(int B, int W, int P, int K) {
   SegWs w;
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  w.goff_off = take((size_t)B * (P + 2) * sizeof(int));   // part offsets [P+1] | unit-weight flag
+  w.goff_off = take((size_t)B * goff_stride(P) * sizeof(int));   // part offsets [P+1] | unit-weight flag | parts by size [32]
   w.lstart_off = take((size_t)B * ((size_t)W * W + 1) * sizeof(int));
   w.lrec_off = take((size_t)B * K * sizeof(uint2));
   w.total = off;
@@ -2793,12 +2823,14 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
   const SegWs ws = seg_ws_layout(B, W, P, K);
   const int S = seg_slots(P, K);
   const char *base = reinterpret_cast<const char *>(workspace);
-  // SMPLR_RASTER=1: the one-pixel-per-lane kernel of rounds 1-3 (kept for A/B runs); SMPLR_RASTER_NG: part ranges per
-  // pixel of the two-pixel kernel (4: 512-thread blocks, 8: 1 024)
+  // SMPLR_RASTER=1: the one-pixel-per-lane kernel of rounds 1-3 (kept for A/B runs); SMPLR_RASTER_SHAPE: the two-pixel
+  // kernel's block, 0 = by batch (below), 1 = 128 pair-lanes x 8 part ranges, 2 = 64 x 10, 3 = 128 x 4
   static const int version = getenv("SMPLR_RASTER") ? atoi(getenv("SMPLR_RASTER")) : 2;
-  static const int ng2 = getenv("SMPLR_RASTER_NG") ? atoi(getenv("SMPLR_RASTER_NG")) : 8;
+  static const int shape_env = getenv("SMPLR_RASTER_SHAPE") ? atoi(getenv("SMPLR_RASTER_SHAPE")) : 0;
   if (version != 1) {
-    const int nl = ((W + 1) / 2) * W, nt2 = (nl + PLN - 1) / PLN;
+    const int shape = shape_env ? shape_env : raster2_shape(B, W);
+    const int pl = shape == 2 ? 64 : PLN;
+    const int nl = ((W + 1) / 2) * W, nt2 = (nl + pl - 1) / pl;
     const int grid2 = 8 * ((B + 7) / 8) * nt2;
     const unsigned wm = (unsigned)(((1u << 24) + W - 1) / W);
     const float4 *Gp = reinterpret_cast<const float4 *>(rec);
@@ -2811,17 +2843,23 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
       SMPLR_HIP(hipEventCreate(&e0));
       SMPLR_HIP(hipEventCreate(&e1));
     }
-#define SMPLR_RASTER2_LAUNCH(LOSS_, NG_)                                                                            \
+#define SMPLR_RASTER2_LAUNCH(LOSS_, NG_, PL_)                                                                       \
   {                                                                                                                 \
     if (kernel_ms)                                                                                                  \
-      hipExtLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_>), dim3(grid2), dim3(PLN * NG_), 0, as_stream(stream), e0, \
-                            e1, 0, Gp, goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo);                         \
+      hipExtLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_, PL_>), dim3(grid2), dim3(PL_ * NG_), 0, as_stream(stream), \
+                            e0, e1, 0, Gp, goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo);                 \
     else                                                                                                            \
-      hipLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_>), dim3(grid2), dim3(PLN * NG_), 0, as_stream(stream), Gp,  \
-                         goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo);                                   \
+      hipLaunchKernelGGL((raster2_fwd_kernel<LOSS_, NG_, PL_>), dim3(grid2), dim3(PL_ * NG_), 0, as_stream(stream), \
+                         Gp, goffp, lsp, lrp, P, K, S, W, B, nt2, seg, argp, wm, lo);                               \
   }
-    if (with_loss) { if (ng2 == 4) SMPLR_RASTER2_LAUNCH(true, 4) else SMPLR_RASTER2_LAUNCH(true, 8) }
-    else { if (ng2 == 4) SMPLR_RASTER2_LAUNCH(false, 4) else SMPLR_RASTER2_LAUNCH(false, 8) }
+#define SMPLR_RASTER2_SHAPES(LOSS_)                                                                                 \
+  {                                                                                                                 \
+    if (shape == 2) SMPLR_RASTER2_LAUNCH(LOSS_, 10, 64)                                                             \
+    else if (shape == 3) SMPLR_RASTER2_LAUNCH(LOSS_, 4, 128)                                                        \
+    else SMPLR_RASTER2_LAUNCH(LOSS_, 8, 128)                                                                        \
+  }
+    if (with_loss) SMPLR_RASTER2_SHAPES(true) else SMPLR_RASTER2_SHAPES(false)
+#undef SMPLR_RASTER2_SHAPES
 #undef SMPLR_RASTER2_LAUNCH
     SMPLR_LAUNCH_CHECK(fn);
     if (kernel_ms) {

@@ -41,7 +41,7 @@ def main():
           % (np.median(scan), np.percentile(scan, 10), np.percentile(scan, 90),
              np.median(scan.max(1) / scan.mean(1)), np.percentile(scan.max(1) / scan.mean(1), 90)))
     g = t[..., 8]
-    for k in range(4):
+    for k in range(8):
         sel = scan[g == k]
         print("  range %d: waves %d, scan median %d p90 %d, parts median %d" % (k, sel.size, np.median(sel), np.percentile(sel, 90),
                                                                               np.median(t[..., 7][g == k])))
