@@ -20,7 +20,7 @@ def h(t):
 def main():
     dev = torch.device("cuda", 0)
     model = synthetic_smpl_model(1234)
-    for W, B, vs in [(48, 1, 1), (48, 5, 1), (48, 33, 1), (48, 128, 1), (32, 7, 2), (64, 40, 1)]:
+    for W, B, vs in [(48, 1, 1), (48, 5, 1), (48, 33, 1), (48, 128, 1), (32, 7, 2), (64, 40, 1), (48, 520, 1)]:
         dec = SMPLDecoder(model, img_wh=W, vertex_sampling=vs, deterministic=True).to(dev)
         g = torch.Generator(device="cpu").manual_seed(100 + B)
         x = torch.tensor(bench.make_x(B, W, 11 + B), device=dev, requires_grad=True)
