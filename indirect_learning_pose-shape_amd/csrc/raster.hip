@@ -1009,7 +1009,11 @@ __global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel
 //    adds per 16 records instead of two per 8; the group id that is tracked is a scalar counter;
 //  * the table is built straight from the global records (thread = record: u and R - 1 squares) behind ONE barrier
 //    (was: copy, barrier, build, barrier);
-//  * the winner re-scan decodes nothing (the tracked id IS the group index).
+//  * the winner re-scan decodes nothing (the tracked id IS the group index);
+//  * the waves of a pixel slice share a list of the parts, largest first (seg_bin_kernel ranks them), and draw from
+//    it as they finish (scan2_parts): the block's longest wave runs 1.11 x its mean instead of 1.32 x;
+//  * two block shapes, PL pair-lanes x NG2 part ranges: 128 x 8 (two blocks per CU) and 64 x 10 (three) for batches
+//    that would not fill two rounds of the large one (raster2_shape).
 // Keys, tie rules, merge and write-out are raster_fwd_kernel's, expression for expression: outputs are bit-identical
 // (tools/probes/seg_hash.py).  Blocks whose tables do not fit (list longer than TREC(R), a weight other than 1, more
 // than 10 image rows under the block) walk the global record list with scalar loads - exact, slow, rare.

@@ -1,6 +1,6 @@
 #!/bin/bash
 # bash tools/ab_env.sh KERNEL_SUBSTRING[,..] "BATCHES" "ENV1" "ENV2" ...: rocprofv3 average of the named kernels of the eager
-# bench step under each environment setting (e.g. "SMPLR_RASTER=1" "SMPLR_RASTER=2 SMPLR_RASTER_NG=4"), per batch size.
+# bench step under each environment setting (e.g. "SMPLR_RASTER=1" "SMPLR_RASTER=2 SMPLR_RASTER_SHAPE=3"), per batch size.
 # The program after `--` is python3 itself (never env / bash -c: see the GPU box's exec rule); settings are exported here.
 cd "$GRAFT_REPO_ROOT"; K=$1; BS=$2; shift; shift
 i=0
