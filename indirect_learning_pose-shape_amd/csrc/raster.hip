@@ -36,6 +36,10 @@
 
 namespace smplr {
 __host__ __device__ constexpr int goff_stride(int P) { return P + 2 + 32; }   // ints per mesh in `goff`
+#ifndef SMPLR_BIN_Q0
+#define SMPLR_BIN_Q0 3
+#endif
+constexpr int BIN_Q0 = SMPLR_BIN_Q0;   // seg_bin_kernel<.., SKIN>: vertices per thread whose operands are requested before the first barrier
 
 constexpr int CH = SMPLR_CHUNK;      // 8: silhouette list padding
 static int set_lds_attr(const void *fn, size_t lds);
@@ -168,8 +172,11 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     const float *c = sk.cam + (size_t)n * sk.x_stride;
     c0 = c[0]; c1 = c[1]; c2 = c[2]; c3 = c[3];
     const float *vp = sk.v_posed + (size_t)n * VP * 3;
+    // (the first BIN_Q0 vertices' operands here, the rest behind the barrier: the CU's address unit takes 7.5 k clocks
+    // for all 35 requests of every thread, and the skinning that follows is bound by LDS reads - the later vertices'
+    // requests are worked off under the first ones' skinning instead of in front of the barrier)
 #pragma unroll
-    for (int q = 0; q < VPT; ++q) {
+    for (int q = 0; q < BIN_Q0; ++q) {
       const int v = min(tid + q * BIN_T, VP - 1);
       const float4 *tp = reinterpret_cast<const float4 *>(sk.top4 + (size_t)v * 8);
       tw[q] = tp[0];
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   if (tid <= P) s_poff[tid] = part_off[tid];
   if (tid == 0) { s_nonunit = 0; s_any_empty = 0; }
   for (int i = tid; i < npix; i += BIN_T) s_cnt[i] = 0;
-  if (vslot)                                                  // block-uniform
+  if (vslot && !SKIN)                                         // block-uniform
     for (int i = tid; i < VP; i += BIN_T) vsl[i] = -1;
   if (VIS) {
     for (int i = tid; i < cells; i += BIN_T) zbuf[i] = 0ull;
@@ -201,6 +208,20 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
   __syncthreads();
   SMPLR_TL_STAMP(2);
   if (SKIN) {
+    const float *vp = sk.v_posed + (size_t)n * VP * 3;
+#pragma unroll
+    for (int q = BIN_Q0; q < VPT; ++q) {
+      const int v = min(tid + q * BIN_T, VP - 1);
+      const float4 *tp = reinterpret_cast<const float4 *>(sk.top4 + (size_t)v * 8);
+      tw[q] = tp[0];
+      tj[q] = tp[1];
+      vu[q] = vp[v * 3 + 0];
+      vv[q] = vp[v * 3 + 1];
+      vz[q] = vp[v * 3 + 2];
+    }
+    if (vslot)                                                // block-uniform
+      for (int i = tid; i < VP; i += BIN_T) vsl[i] = -1;
+    __builtin_amdgcn_sched_barrier(0);
     float *vo = sk.verts + (size_t)n * VP * 3, *po = sk.proj + (size_t)n * VP * 3;
 #pragma unroll
     for (int q = 0; q < VPT; ++q) {
