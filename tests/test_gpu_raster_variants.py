@@ -1,6 +1,6 @@
 """The part rasteriser's launch forms give the same bits: the two-pixel kernel in both block shapes (128 pair-lanes x 8
 part ranges, 64 x 10: `raster2_shape` picks by batch) against the one-pixel kernel of rounds 1-3, over the probe's
-nine (W, B, vertex sampling, mesh scale) cases, visibility path and explicit all-visible / none-visible masks.
+twelve (W, B, vertex sampling, mesh scale) cases, visibility path and explicit all-visible / none-visible masks.
 The forms are chosen by environment variables the library reads once, so each runs in a child process."""
 import os
 import subprocess
@@ -18,7 +18,7 @@ def _hashes(env):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("W=")]
-    assert len(lines) == 9, r.stdout
+    assert len(lines) == 12, r.stdout
     return lines
 
 

@@ -48,6 +48,17 @@ def main():
     wait = d[..., 5] - d[..., 4]
     print("wait at the barrier after the scan: median %d, p90 %d" % (np.median(wait), np.percentile(wait, 90)))
     placement(t)
+    # when workgroups enter and leave (10 ns ticks after the launch's first wave; exit = entry + life at 2.4 GHz)
+    wall = t[:, 0, 28]
+    rel = (wall - wall.min()) & 0xFFFFFFFF
+    life = d[..., 6].max(1)
+    end = rel + life / 24.0
+    order = np.argsort(rel)
+    for name, sel in (("first 512 to enter", order[:512]), ("next 512", order[512:1024]), ("last 128", order[1024:])):
+        if len(sel):
+            print("  %-18s enter p10/50/90 = %5d %5d %5d ticks, life p10/50/90 = %5d %5d %5d clocks, leave p50/max = %5d %5d ticks"
+                  % (name, *[int(np.percentile(rel[sel], q)) for q in (10, 50, 90)],
+                     *[int(np.percentile(life[sel], q)) for q in (10, 50, 90)], int(np.median(end[sel])), int(end[sel].max())))
 
 
 if __name__ == "__main__":

@@ -22,7 +22,9 @@ def main():
     model = synthetic_smpl_model(1234)
     consts = ops.SMPLConstants.from_model(model, dev)
     for W, B, vs, scale in [(48, 16, 1, 1.0), (48, 5, 1, 2.5), (64, 8, 1, 1.0), (32, 4, 1, 1.0), (96, 3, 1, 1.0),
-                            (48, 6, 2, 1.0), (40, 3, 1, 0.5), (128, 2, 1, 1.0), (48, 4, 1, 6.0)]:
+                            (48, 6, 2, 1.0), (40, 3, 1, 0.5), (128, 2, 1, 1.0), (48, 4, 1, 6.0),
+                            # (batches that take the large block shape by default)
+                            (48, 128, 1, 1.0), (48, 70, 1, 1.3), (64, 37, 1, 1.0)]:
         pt = ops.get_part_table(vs, dev, consts.V)
         xn = bench.make_x(B, W, 7 + W + B)
         xn[:, 0] *= scale                      # camera scale: bigger mesh -> more visible records
