@@ -1462,6 +1462,7 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
 // the order in which a block's strips reach a slot's LDS accumulator (last-ulp rounding).
 // (SB_SLOTS = 4096 accumulators per window, SB_NWIN = 5 windows, 8 or 24 rows per block by batch size: common.h)
 constexpr int SB_U = 8;          // pixels in flight per lane
+constexpr int SB_PF = 12;        // pixels of a row requested at kernel entry (>= SB_U)
 
 // (unconditional: a run that ends has a non-zero sum except by cancellation, and the walk starts on slot 0 with a sum
 // of zero, so the tests that used to guard this - slot valid, sum non-zero - only cost their instructions, in a kernel
@@ -1607,7 +1608,6 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
   int a[NB][U];
   float g[NB][U];
   float4 rv[NB][U];
-  static_assert(U <= SB_U, "the first batch comes from the SB_U pixels requested at kernel entry");
   int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
   float sx = 0.0f, sy = 0.0f;
 #ifdef SMPLR_TL
@@ -1633,12 +1633,14 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
     g[b_][u] = g[b_][u] - __shfl((a[b_][u] == 1) ? g[b_][u] : 0.0f, 0, 32);                                     \
     rv[b_][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, a[b_][u] * 16, 0, 0));    \
   }
+  static_assert(NB > 1 && 2 * U <= SB_PF, "the first TWO batches come from the SB_PF pixels requested at kernel entry");
 #pragma unroll
-  for (int u = 0; u < U; ++u) {                  // batch 0 was requested at kernel entry (its first U pixels)
-    a[0][u] = pa[u];
+  for (int u = 0; u < U; ++u) {                  // batches 0 and 1 were requested at kernel entry: the walk starts with
+    a[0][u] = pa[u];                             // both gathers instead of a round trip for batch 1's rows
     g[0][u] = pg[u];
+    a[1][u] = pa[U + u];
+    g[1][u] = pg[U + u];
   }
-  if (NB > 1) { SMPLR_SB_LOAD(1) }
   SMPLR_SB_GATHER(0)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -1896,16 +1898,19 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
   const bool fast = C == 32 && W % SB_U == 0;               // block-uniform
   // The first batch of the row walk is requested here, behind the header: its trip to HBM (2 us at the head of a
   // 20 us kernel that otherwise streams at 4.8 TB/s) then runs under the zeroing of the accumulators and its barrier.
-  int pa[SB_U];
-  float pg[SB_U];
+  // (round 4: the first SB_PF = 12 pixels - two batches of the pipelined walk, which then starts with two gathers)
+  int pa[SB_PF];
+  float pg[SB_PF];
   float warm = 0.0f;                                          // LOSS: touches the first batch's stats (see seg_bwd_row_loss)
 #pragma unroll
-  for (int u = 0; u < SB_U; ++u) { pa[u] = 0; pg[u] = 0.0f; }
+  for (int u = 0; u < SB_PF; ++u) { pa[u] = 0; pg[u] = 0.0f; }
   if (fast && ro < W) {
 #pragma unroll
-    for (int u = 0; u < SB_U; ++u) {
-      pa[u] = arg[(row0 + u) * 32 + ch];
-      pg[u] = LOSS ? li.dloss[row0 + u] : dseg[(row0 + u) * 32 + ch];
+    for (int u = 0; u < SB_PF; ++u) {
+      if (LOSS && u >= SB_U) continue;                        // (the loss walk takes its first batch only)
+      const int uu = min(u, W - 1);
+      pa[u] = arg[(row0 + uu) * 32 + ch];
+      pg[u] = LOSS ? li.dloss[row0 + uu] : dseg[(row0 + uu) * 32 + ch];
     }
     if (LOSS) warm = reinterpret_cast<const float *>(li.stats + row0)[ch];
   }
@@ -1957,7 +1962,7 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     if (ro < W) {
       // (the compiler would otherwise start on the first batch - and wait for it - in front of the barrier)
 #pragma unroll
-      for (int u = 0; u < SB_U; ++u) asm volatile("" : "+v"(pa[u]), "+v"(pg[u]));
+      for (int u = 0; u < SB_PF; ++u) asm volatile("" : "+v"(pa[u]), "+v"(pg[u]));
       if (LOSS) {
         asm volatile("" : "+v"(warm));
         if (nwin == 1 && fast && W == 48 && pipe)
