@@ -835,7 +835,10 @@ def main():
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 step()
-            ms_graph1 = _timed_steps(g1.replay, 20, args.steps, dist, dev, backend, torch.cuda.synchronize) / args.steps * 1e3
+            # (K host launches per window: the smallest of three windows - a busy host core shows up here first)
+            g1w = [_timed_steps(g1.replay, 20 if i == 0 else 0, args.steps, dist, dev, backend, torch.cuda.synchronize)
+                   / args.steps * 1e3 for i in range(3)]
+            ms_graph1 = min(g1w)
             del g1
         except Exception as e:
             sys.stderr.write("bench: one-step graph failed (%s)\n" % e)
