@@ -1094,7 +1094,11 @@ __device__ __forceinline__ int scan2_parts(const char *tb, int offv, int ordv, i
                                            unsigned va, f32x2 fc2, float *myS, short *myA) {
   constexpr int GB = R * 16;             // bytes per group
   int done = 1, r = g;
+#ifdef SMPLR_KO2_SCAN
+  if (r < P) {
+#else
   while (r < P) {
+#endif
     int rn = 0;
     if (done >= R2_STATIC) {
       if (lane0) rn = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1194,7 +1198,11 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
   float4 rcs[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
+#ifdef SMPLR_KO2_RECORDS                                 // (knock-out builds, tools/ab_kernel_b.sh: wrong results on purpose)
+    rcs[h] = make_float4((float)(tid & 31), (float)(tid >> 5), 1.f, 0.f);
+#else
     rcs[h] = (h == 0 || tid + h * NT < trec) ? Gn[min(tid + h * NT, S - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
   const bool tbl = unit_m && nrows <= R2_MAX - 1 && lbase <= trec;     // block-uniform
   // merge / write-out items: item e = it * NT + tid is tile pixel e / 4 (= 2 x pair-lane + row of the pair); its lane
   // sub4 = e % 4 takes the channel chunks sub4 and sub4 + 4 (channels 4 sub4 .. and 16 + 4 sub4 ..): four lanes per
@@ -1331,7 +1339,11 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
       const int l1 = l1a[it];
       int i = l0a[it] + sub;
       uint2 rec = lr0[it];
+#ifdef SMPLR_KO2_MERGE
+      while (false) {
+#else
       while (__any(i < l1)) {
+#endif
         const uint2 nxt = lrecn[min(i + 4, K - 1)];        // next step's record, in flight during this one
         if (i < l1) {
           const int sc = __float_as_int(fast_exp_neg(__uint_as_float(rec.x)));
@@ -1390,7 +1402,11 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
       po = (unsigned)((W - 1 - rr) * W + cc);              // rows flipped (:68); mesh base + 32-bit offset
     }
     if (LOSS) po_[it] = po;
+#ifdef SMPLR_KO2_WRITE
+    if (qq >= 0 && sum == 12345.678f) {
+#else
     if (qq >= 0) {
+#endif
       if (lo.vmax && sub == 0) lo.vmax[(size_t)n * npix + po] = vmx;
       float *so = seg + (size_t)n * npix * C + po * (unsigned)C;
       if (LOSS && !seg) {                                  // (block-uniform) the scores stay on the chip
