@@ -1099,9 +1099,16 @@ __device__ __forceinline__ int scan2_parts(const char *tb, int offv, int ordv, i
 #else
   while (r < P) {
 #endif
+    // (the draw as a bare ds_add_rtn_u32 from lane 0: through __hip_atomic_fetch_add the compiler's wave-aggregation of
+    // atomics - mbcnt, a second exec detour, a count, a broadcast - wrapped it in a dozen instructions and, worse, waited
+    // for the answer on the spot; here nothing waits before the part in hand has been scanned.  LDS operations return in
+    // order, so every wait the compiler places for its own reads covers this older one too.)
     int rn = 0;
     if (done >= R2_STATIC) {
-      if (lane0) rn = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane0) {
+        const unsigned ca = (unsigned)(size_t)(__attribute__((address_space(3))) int *)ctr;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(rn) : "v"(ca), "v"(1) : "memory");
+      }
     }
     const int p = __builtin_amdgcn_readlane(ordv, r);
     const int beg = __builtin_amdgcn_readlane(offv, p), end = __builtin_amdgcn_readlane(offv, p + 1);
@@ -1141,6 +1148,7 @@ __device__ __forceinline__ int scan2_parts(const char *tb, int offv, int ordv, i
     myA[p] = (short)sA_;
     myA[ALD + p] = (short)sB_;
     const int sn = (done & 1) ? (done + 1) * NG - 1 - g : done * NG + g;       // the wave's done-th entry of the static deal
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rn) : : "memory");               // (the draw has long returned)
     r = (done < R2_STATIC) ? sn : __builtin_amdgcn_readfirstlane(rn);
     ++done;
   }
