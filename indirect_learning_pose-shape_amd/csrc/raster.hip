@@ -1044,7 +1044,9 @@ constexpr int PLN = 128;                 // pair-lanes per block: 2 x 64 (the la
 // half-filled: up to about two rounds of the large shape (512 blocks on 256 CUs at a time).
 __host__ inline int raster2_shape(int B, int W) {
   const long long nl = (long long)((W + 1) / 2) * W, blocks1 = (long long)B * ((nl + PLN - 1) / PLN);
-  return blocks1 <= 900 ? 2 : 1;          // (W = 48: up to 100 meshes; step A/B at B = 96: -1.2 %, at 112: +1.5 %)
+  // (W = 48: up to 100 meshes; step A/B at B = 96: -1.2 %, at 112: +1.5 %.  W = 64, where a mesh has 60 % more records in
+  // reach and 32 small blocks to build a table for: the small shape loses at every batch - B = 16: +6 %, 48: +12 %)
+  return (W <= 48 && blocks1 <= 900) ? 2 : 1;
 }
 #ifndef SMPLR_R2_STATIC
 #define SMPLR_R2_STATIC 1
