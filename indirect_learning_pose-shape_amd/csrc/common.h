@@ -112,12 +112,19 @@ constexpr int SB_ROWS_BIG = 24;  // ... and while that gives every CU one to fou
 inline int seg_bwd_rows(int B, int W) {
   // seg_bwd + skin_bwd at W = 48, 8 against 24 rows: B = 128 42.4 / 41.0 us, 256: 81.9 / 78.3, 512: 153.3 / 156.9,
   // 2048: 578 / 601 (round 3's kernels) - the tall blocks pay off from one block per CU on
-  const long long n = (long long)B * ((W + SB_ROWS_BIG - 1) / SB_ROWS_BIG);
   // (round 4, with the pipelined row walk: tall blocks at every batch from there on - B = 2 048: seg_bwd 260 -> 289 us,
   // skin_bwd 261 -> 233 (two partials to gather per vertex instead of six), step 1.442 -> 1.432 ms; B = 512: 0.3897 -> 0.3871;
   // SMPLR_SEGBWD_TALL_TO=1024 restores round 3's upper end)
   static const long long tall_to = getenv("SMPLR_SEGBWD_TALL_TO") ? atoll(getenv("SMPLR_SEGBWD_TALL_TO")) : (1ll << 40);
-  return (n >= 256 && n < tall_to) ? SB_ROWS_BIG : SB_ROWS;
+  static const int tall_env = getenv("SMPLR_SEGBWD_TALL_ROWS") ? atoi(getenv("SMPLR_SEGBWD_TALL_ROWS")) : 0;   // (A/B runs: 2..24)
+  // the tall height divides the image where it can (W = 64: 24 + 24 + 16 rows left the launch waiting for its two
+  // full-height blocks per mesh - whole step at B = 128: 0.1698 ms with 24, 0.1691 with 8, 0.1605 with 16 rows)
+  int tall = SB_ROWS_BIG;
+  for (int r = SB_ROWS_BIG; r >= 12; r -= 2)
+    if (W % r == 0) { tall = r; break; }
+  if (tall_env >= 2 && tall_env <= SB_ROWS_BIG) tall = tall_env;
+  const long long n = (long long)B * ((W + tall - 1) / tall);          // tall blocks of the launch
+  return (n >= 256 && n < tall_to) ? tall : SB_ROWS;
 }
 struct SegGrad { const float *part; const int16_t *vslot; int nsplit; };
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,

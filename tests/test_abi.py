@@ -69,13 +69,15 @@ def test_argument_counts_match_header():
 
 def test_seg_bwd_row_blocks_by_batch():
     """The segmentation backward cuts a mesh's image into row blocks of 8 rows, or of 24 from the batch on that gives
-    every CU (256) a block of 24; the workspace is sized for whichever applies (host-side arithmetic only)."""
+    every CU (256) a tall block (24 rows, or the largest even divisor of W from 12 to 24); the workspace is sized for whichever applies (host-side arithmetic only)."""
     from ilps_amd import _lib
     lib = _lib.load()
     assert lib.smplr_seg_bwd_nsplit(1, 48) == 6 and lib.smplr_seg_bwd_nsplit(127, 48) == 6
     assert lib.smplr_seg_bwd_nsplit(128, 48) == 2 and lib.smplr_seg_bwd_nsplit(511, 48) == 2
     assert lib.smplr_seg_bwd_nsplit(512, 48) == 2 and lib.smplr_seg_bwd_nsplit(2048, 48) == 2
     assert lib.smplr_seg_bwd_nsplit(64, 96) == 4 and lib.smplr_seg_bwd_nsplit(63, 96) == 12
+    # the tall height divides the image where it can: W = 64 -> 16 rows (4 blocks per mesh), from 64 meshes on
+    assert lib.smplr_seg_bwd_nsplit(128, 64) == 4 and lib.smplr_seg_bwd_nsplit(64, 64) == 4 and lib.smplr_seg_bwd_nsplit(63, 64) == 8
     assert lib.smplr_seg_bwd_nsplit(300, 20) == 1 and lib.smplr_seg_bwd_nsplit(0, 48) == 0
     for B, W in ((1, 48), (128, 48), (64, 96), (5, 50)):
         assert lib.smplr_seg_bwd_workspace(B, W) == B * lib.smplr_seg_bwd_nsplit(B, W) * 5 * 4096 * 2 * 4
