@@ -897,11 +897,15 @@ class DecoderOpts:
 # (tools/probes/blend_big.py); whole steps on one box: B = 256 0.2237 (one launch) against 0.230 ms, B = 384 0.349
 # against 0.3427.  Bit-identical either way.
 POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "320"))
-# Batch below which the binning workgroups skin their own vertices (one launch less, no re-read of proj): with one
-# workgroup per mesh the skinning lengthens a latency chain that a half-empty chip does not feel - B = 128: -5 us,
-# B = 192: 0.1906 against 0.1937 ms per step - and that every CU pays once the chip is full: B = 256: 0.2222-0.225
-# against 0.2164-0.2181 for the separate skinning launch, 512: 0.425 / 0.403-0.411, 2 048: 1.508 / 1.480 (same box).
-FUSE_SKIN_BELOW_B = int(os.environ.get("SMPLR_FUSE_SKIN_BELOW_B", "256"))
+# Batches at which the binning workgroups skin their own vertices (one launch less, no re-read of proj): with one
+# workgroup per mesh the skinning lengthens a latency chain that a half-empty chip does not feel - B = 128: -5 us - and
+# that every CU pays once the chip is full.  Round 4 (vslot straight to memory, requests split around the first barrier)
+# moved the crossover: whole step, fused / separate skinning launch, same box: B = 256 0.2047 / 0.2149 ms, 384 0.3256 /
+# 0.3323, 448 0.3829 / 0.3819, 512 0.3988 / 0.3894, 640 0.5103 / 0.5017, 768 0.5824 / 0.5832, 1 024 0.7144 / 0.7240,
+# 1 536 1.1352 / 1.1468, 2 048 1.3998 / 1.4347 - fused below 448 meshes and again from 768 on (where the separate
+# launch's re-read of proj and verts is what every CU pays).
+FUSE_SKIN_BELOW_B = int(os.environ.get("SMPLR_FUSE_SKIN_BELOW_B", "448"))
+FUSE_SKIN_FROM_B = int(os.environ.get("SMPLR_FUSE_SKIN_FROM_B", "768"))
 
 
 SILH_HINT_MAX_W = 48     # smplr_silh_fwd_hint uses the hint in silh_px_kernel only (W <= 48, raster.hip)
@@ -991,7 +995,7 @@ class DecoderFn(torch.autograd.Function):
         # vertex is rasterised and the mesh fits the binning workgroup's LDS; SMPLR_FUSE_SKIN=0 keeps the two calls
         fuse_skin = (opts.seg and consts.lbs_top4 is not None and vs == 1
                      and bool(lib.smplr_skin_vis_seg_fits(V, W, int(grid_wh)))
-                     and B < FUSE_SKIN_BELOW_B and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
+                     and (B < FUSE_SKIN_BELOW_B or B >= FUSE_SKIN_FROM_B) and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0")
         sl = lambda t, lo, hi: None if t is None else t[lo:hi]
 
         def run(lo, hi):

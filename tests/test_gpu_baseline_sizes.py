@@ -362,8 +362,8 @@ def test_global_batch_1024_row_independence(smpl_model):
 
 def test_pose_and_blend_in_one_launch_or_two(smpl_model, monkeypatch):
     """The decoder's forward runs pose + blend as one launch below ops.POSE_BLEND_SPLIT_B meshes and as two from there
-    on, and skins inside the binning workgroups below ops.FUSE_SKIN_BELOW_B meshes and in a launch of its own from
-    there on: the same bits either way (thresholds moved under a small batch instead of running a large one)."""
+    on, and skins inside the binning workgroups below ops.FUSE_SKIN_BELOW_B meshes (and again from ops.FUSE_SKIN_FROM_B on)
+    and in a launch of its own in between: the same bits either way (thresholds moved under a small batch instead of running a large one)."""
     from ilps_amd import ops
     from ilps_amd.decoder import SMPLDecoder
     B, W = 9, 48
@@ -374,6 +374,7 @@ def test_pose_and_blend_in_one_launch_or_two(smpl_model, monkeypatch):
         monkeypatch.setattr(ops, "POSE_BLEND_SPLIT_B", 4)
         two = dec(x)
         monkeypatch.setattr(ops, "FUSE_SKIN_BELOW_B", 4)
+        monkeypatch.setattr(ops, "FUSE_SKIN_FROM_B", 1 << 30)
         three = dec(x)
     for k in ("verts", "projects", "mask", "seg", "J_transformed"):
         assert torch.equal(one[k], two[k]) and torch.equal(one[k], three[k]), k
