@@ -895,8 +895,9 @@ class DecoderOpts:
 # round of workgroups - B = 128: 17.3 us against 7.1 + 13.0 - and loses once it is many, because that LDS allows one
 # workgroup per CU where the plain GEMM fits two: B = 512: 52.4 against 7.2 + 42.1, B = 2 048: 191 against 9.2 + 136.4
 # (tools/probes/blend_big.py); whole steps on one box: B = 256 0.2237 (one launch) against 0.230 ms, B = 384 0.349
-# against 0.3427.  Bit-identical either way.
-POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "320"))
+# against 0.3427.  Bit-identical either way.  (Round 4, re-measured, one launch / two: B = 256 0.2149 / 0.2185 ms, 320
+# 0.3097 / 0.3162, 384 0.3300 / 0.3323, 448 0.3990 / 0.3844, 512 0.3985 / 0.3853: the crossover lies at about 400.)
+POSE_BLEND_SPLIT_B = int(os.environ.get("SMPLR_POSE_BLEND_SPLIT_B", "400"))
 # Batches at which the binning workgroups skin their own vertices (one launch less, no re-read of proj): with one
 # workgroup per mesh the skinning lengthens a latency chain that a half-empty chip does not feel - B = 128: -5 us - and
 # that every CU pays once the chip is full.  Round 4 (vslot straight to memory, requests split around the first barrier)
