@@ -1042,11 +1042,13 @@ constexpr int PLN = 128;                 // pair-lanes per block: 2 x 64 (the la
 // The block shape by batch: 1 = 128 pair-lanes x 8 part ranges (two blocks per CU), 2 = 64 x 10 (three per CU).  The
 // small blocks cost a second table build per 256 pixels and pay while the large ones would leave CUs idle or
 // half-filled: up to about two rounds of the large shape (512 blocks on 256 CUs at a time).
-__host__ inline int raster2_shape(int B, int W) {
+__host__ inline int raster2_shape(int B, int W, int K) {
   const long long nl = (long long)((W + 1) / 2) * W, blocks1 = (long long)B * ((nl + PLN - 1) / PLN);
   // (W = 48: up to 100 meshes; step A/B at B = 96: -1.2 %, at 112: +1.5 %.  W = 64, where a mesh has 60 % more records in
-  // reach and 32 small blocks to build a table for: the small shape loses at every batch - B = 16: +6 %, 48: +12 %)
-  return (W <= 48 && blocks1 <= 900) ? 2 : 1;
+  // reach and 32 small blocks to build a table for: the small shape loses at every batch - B = 16: +6 %, 48: +12 %.
+  // With every fifth vertex (K = 1 376, 400 records in reach) it loses as well - B = 96: +1.8 %, 32: +0.4 %: the full
+  // part table only)
+  return (W <= 48 && K >= 6000 && blocks1 <= 900) ? 2 : 1;
 }
 #ifndef SMPLR_R2_STATIC
 #define SMPLR_R2_STATIC 1
@@ -2884,7 +2886,7 @@ static int seg_raster_impl(const char *fn, int B, int W, int P, int K, const voi
   static const int version = getenv("SMPLR_RASTER") ? atoi(getenv("SMPLR_RASTER")) : 2;
   static const int shape_env = getenv("SMPLR_RASTER_SHAPE") ? atoi(getenv("SMPLR_RASTER_SHAPE")) : 0;
   if (version != 1) {
-    const int shape = shape_env ? shape_env : raster2_shape(B, W);
+    const int shape = shape_env ? shape_env : raster2_shape(B, W, K);
     const int pl = shape == 2 ? 64 : PLN;
     const int nl = ((W + 1) / 2) * W, nt2 = (nl + pl - 1) / pl;
     const int grid2 = 8 * ((B + 7) / 8) * nt2;
