@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SMPLR_ABI_VERSION 6
+#define SMPLR_ABI_VERSION 7
 #define SMPLR_NJ 24            /* joints                                   */
 #define SMPLR_KPAD 220         /* 10 betas + 207 pose features, padded     */
 #define SMPLR_CHUNK 8          /* raster vertex-list padding granule       */
@@ -189,8 +189,9 @@ int smplr_visibility(const float *proj, int B, int VP, int grid_wh, int ref_comp
  *   underflow threshold (mask*d >= 104) are exactly 0, as they are in fp32 arithmetic.
  * rec (B,S,4) fp32, S = smplr_seg_slots(P,K): the mesh's compact record list
  *   (u, v, mask^2, vertex position as int32 bits) - first the far-reaching (visible) vertices,
- *   part-major, then the nearest-pixel-only ones; the last slot's first word holds the number
- *   of used slots.  Only the used prefix (and that header) is written.
+ *   part-major, then the nearest-pixel-only ones; the last slot is a header of int32 words:
+ *   [0] used slots, [1] 1 if some far-reaching weight is not 1, [2] length of the far-reaching list (padded per
+ *   part to 4: smplr_seg_raster_plan), [3] -1.  Only the used prefix and the header are written.
  * arg (B,W,W,32) int16, slot = channel: [0] = 1 iff 0 <= sum_p <= 1 (the clip's pass-through
  *   gate); [1+p] = index into rec[b] of the maximising vertex of part p, or -1 when no vertex
  *   contributes a non-zero score.  rec + arg are what the backward needs (no proj/mask/seg).
@@ -246,6 +247,20 @@ int smplr_seg_raster(int B, int W, int P, int K, const void *workspace, const fl
  * include.  Not capturable, synchronises: never on the product path.                                            */
 int smplr_seg_raster_timed(int B, int W, int P, int K, const void *workspace, const float *rec, float *seg,
                            int16_t *arg, float *kernel_ms, void *stream);
+
+/* How smplr_seg_raster will run a batch - host arithmetic only, nothing is launched (bench.py and the tests count
+ * the blocks that need more than one pass over their record list with it; the reference has no counterpart: its
+ * rasteriser, projects_to_seg.py:41-56, materialises every pair).  info[8] receives
+ *   [0] pair-lanes per workgroup, [1] part ranges (waves per 64 pair-lanes), [2] workgroups per mesh (tiles),
+ *   [3] ints per mesh in the workspace's part-offset block, which starts at byte 0 of the workspace: entry [P] of a
+ *       mesh's row is the length of its far-reaching record list, padded per part to 4 (`lbase`), entry [P + 1] is
+ *       non-zero when some far-reaching weight is not 1,
+ *   [4] the largest record table over the tiles, [5] the smallest, [6] 1 if some tile has more image rows under it
+ *       than the table form takes (such tiles walk the list with scalar loads, whatever its length), [7] 0.
+ * tile_records (tiles ints) or NULL: per tile the records ONE pass over the LDS table takes; a unit-weight mesh with
+ * lbase records costs tile t ceil(lbase / tile_records[t]) passes (0 there = the tile is of kind [6]).  Returns the
+ * number of tiles, 0 on bad sizes.                                                                               */
+int smplr_seg_raster_plan(int B, int W, int P, int K, int32_t *info, int32_t *tile_records);
 
 /* dproj (B,VP,3), fully written (z column and unreferenced vertices = 0).  Gradient goes to
  * the first arg-min vertex only (TF splits exact ties); it is 0 where the distance is 0 (TF:

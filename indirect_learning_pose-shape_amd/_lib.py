@@ -13,11 +13,15 @@ from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmplraster_hip.so")
+# SMPLR_LIB_PATH: another build of the library (an A/B run against an older or a variant build, tools/ab_*.sh) - chosen
+# by path, never copied over the product library; its build id is not compared with the sources beside it, and the torch
+# op layer (linked against the product library) is switched off for the process.
+LIB_OVERRIDE = os.environ.get("SMPLR_LIB_PATH") or None
+LIB_PATH = os.path.abspath(LIB_OVERRIDE) if LIB_OVERRIDE else os.path.join(_HERE, "libsmplraster_hip.so")
 
 KPAD = 220
 CHUNK = 8
-ABI_VERSION = 6          # SMPLR_ABI_VERSION of include/smplraster.h
+ABI_VERSION = 7          # SMPLR_ABI_VERSION of include/smplraster.h
 
 P = c_void_p
 I = c_int
@@ -59,6 +63,7 @@ SIGNATURES = {
     "smplr_seg_bin": (c_int, [P, P, I, I, I, I, I, P, P, I, I, P, P, P, P]),
     "smplr_seg_raster": (c_int, [I, I, I, I, P, P, P, P, P]),
     "smplr_seg_raster_timed": (c_int, [I, I, I, I, P, P, P, P, P, P]),
+    "smplr_seg_raster_plan": (c_int, [I, I, I, I, P, P]),
     "smplr_seg_bwd_nsplit": (c_int, [I, I]),
     "smplr_seg_bwd_workspace": (c_size_t, [I, I]),
     "smplr_seg_bwd": (c_int, [P, P, P, I, I, I, I, I, P, P, I, P]),
@@ -140,13 +145,18 @@ def load():
             "`python -c \"import __graft_entry__ as g; g.build()\"` (needs hipcc, gfx950)." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if LIB_OVERRIDE and not hasattr(lib, name):
+            continue                     # (an older build in an A/B run: entry points added since are simply absent)
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.smplr_abi_version() != ABI_VERSION:
+    if lib.smplr_abi_version() != ABI_VERSION and not LIB_OVERRIDE:
         raise RuntimeError("libsmplraster_hip.so ABI version mismatch")
     want, got = source_build_id(), lib.smplr_build_id().decode("ascii")
-    if want is not None and want != got:
+    if LIB_OVERRIDE:
+        import sys
+        sys.stderr.write("[smplraster] SMPLR_LIB_PATH=%s (build %s...): not the product library\n" % (LIB_PATH, got[:12]))
+    elif want is not None and want != got:
         raise RuntimeError(
             "libsmplraster_hip.so was built from other sources than the ones beside it (library %s..., sources "
             "%s...): rebuild with `make -C indirect_learning_pose-shape_amd/csrc`" % (got[:12], want[:12]))

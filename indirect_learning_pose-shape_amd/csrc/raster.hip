@@ -32,6 +32,7 @@
 // accumulators (ds_add_f32) only at run boundaries; per-block slot sums are merged in a fixed
 // order and scattered to the vertices with plain stores (no global atomics, no memset).
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include "common.h"
 
 namespace smplr {
@@ -424,10 +425,12 @@ __global__ __launch_bounds__(BIN_T) void seg_bin_kernel(const float *__restrict_
     }
   }
   SMPLR_TL_STAMP(15);
-  // header: used slots | 1 if some far-reaching record has a weight other than 1 (else the pair loop skips m^2)
+  // header: used slots | 1 if some far-reaching record has a weight other than 1 (else the pair loop skips m^2) | length
+  // of the far-reaching list, padded per part (what the rasteriser's table has to hold: smplr_seg_raster_plan)
   if (tid == 0) goffn[P + 1] = s_nonunit;
   if (tid == 0)
-    Gn[S - 1] = make_float4(__int_as_float(s_gpad[P] + lstartn[npix]), __int_as_float(s_nonunit), 0.f, __int_as_float(-1));
+    Gn[S - 1] = make_float4(__int_as_float(s_gpad[P] + lstartn[npix]), __int_as_float(s_nonunit), __int_as_float(s_gpad[P]),
+                            __int_as_float(-1));
   // sentinels in the padding
   if (tid < P) {
     const int cnt = s_gstart[tid + 1] - s_gstart[tid];
@@ -1159,6 +1162,85 @@ __device__ __forceinline__ int scan2_parts(const char *tb, int offv, int ordv, i
   return done - 1;
 }
 
+// The same for a record list LONGER than the table (round 5): the list goes through the table in chunks of `trec`
+// records, [c0, c1) this time, and a (pixel, part)'s running (smallest key, its record slot) waits in the block's score /
+// arg tiles between chunks.  A part is STARTED by the chunk its first record lies in (the last chunk also starts the parts
+// that begin at the very end of the list: the empty ones), CONTINUED by every later chunk it reaches into, and FINISHED -
+// its key turned into the score - by the chunk its last record lies in.  Keys, the strict '<' across groups and the
+// first-equal rule inside the winning group are scan2_parts': the winner over the chunks is the first record in list order
+// that attains the minimum, bit for bit what one pass over a table of the whole list (or raster_fwd_kernel) gives.  The
+// waves draw the parts as above in every chunk; parts the chunk does not touch cost a draw and two compares.
+template <int R, int NG>
+__device__ __forceinline__ int scan2_parts_chunk(const char *tb, int offv, int ordv, int *ctr, int g, int P, bool lane0,
+                                                 unsigned va, f32x2 fc2, float *myS, short *myA, int c0, int c1,
+                                                 bool last) {
+  constexpr int GB = R * 16;
+  int done = 1, r = g;
+  while (r < P) {
+    int rn = 0;
+    if (done >= R2_STATIC) {
+      if (lane0) {
+        const unsigned ca = (unsigned)(size_t)(__attribute__((address_space(3))) int *)ctr;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(rn) : "v"(ca), "v"(1) : "memory");
+      }
+    }
+    const int p = __builtin_amdgcn_readlane(ordv, r);
+    const int beg = __builtin_amdgcn_readlane(offv, p), end = __builtin_amdgcn_readlane(offv, p + 1);
+    const bool start = beg >= c0 && (beg < c1 || last), cont = beg < c0 && end > c0;       // wave-uniform
+    if (start || cont) {
+      float bestA = INFINITY, bestB = INFINITY;
+      int sA_ = -1, sB_ = -1;
+      if (cont) {
+        bestA = myS[p];
+        bestB = myS[SLD + p];
+        sA_ = myA[p];
+        sB_ = myA[ALD + p];
+      }
+      const int b = max(beg, c0), e = min(end, c1);
+      if (b < e) {
+        int gid = (b - c0) >> 2;                             // group of the TABLE (chunk-relative)
+        const int ngrp = (e - b) >> 2;
+        int gA = -1, gB = -1;                                // no group of this chunk has lowered the minimum yet
+        unsigned vu = (unsigned)gid * GB, vt = vu + va;
+        asm volatile("" : "+v"(vu));
+        asm volatile("" : "+v"(vt));
+        int k = 0;
+        for (; k + 4 <= ngrp; k += 4) {
+          scan2_body<R>(tb, vu, vt, 0, gid, fc2, bestA, bestB, gA, gB);
+          scan2_body<R>(tb, vu, vt, GB, gid + 1, fc2, bestA, bestB, gA, gB);
+          scan2_body<R>(tb, vu, vt, 2 * GB, gid + 2, fc2, bestA, bestB, gA, gB);
+          scan2_body<R>(tb, vu, vt, 3 * GB, gid + 3, fc2, bestA, bestB, gA, gB);
+          vu += 4 * GB;
+          vt += 4 * GB;
+          gid += 4;
+        }
+        if ((ngrp - k) & 2) {
+          scan2_body<R>(tb, vu, vt, 0, gid, fc2, bestA, bestB, gA, gB);
+          scan2_body<R>(tb, vu, vt, GB, gid + 1, fc2, bestA, bestB, gA, gB);
+          vu += 2 * GB;
+          vt += 2 * GB;
+          gid += 2;
+        }
+        if ((ngrp - k) & 1) scan2_body<R>(tb, vu, vt, 0, gid, fc2, bestA, bestB, gA, gB);
+        // (a lane whose minimum this chunk did not lower keeps the slot it came with: the earlier record wins a tie)
+        const int nA = rescan2<R>(tb, max(gA, 0), va, fc2, bestA), nB = rescan2<R>(tb, max(gB, 0), va + 16, fc2, bestB);
+        sA_ = gA >= 0 ? nA + c0 : sA_;
+        sB_ = gB >= 0 ? nB + c0 : sB_;
+      }
+      const bool fin = end <= c1;                            // (the last chunk ends at the list's end: always)
+      myS[p] = fin ? fast_exp_neg(fast_sqrt(bestA)) : bestA;
+      myS[SLD + p] = fin ? fast_exp_neg(fast_sqrt(bestB)) : bestB;
+      myA[p] = (short)sA_;
+      myA[ALD + p] = (short)sB_;
+    }
+    const int sn = (done & 1) ? (done + 1) * NG - 1 - g : done * NG + g;
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rn) : : "memory");
+    r = (done < R2_STATIC) ? sn : __builtin_amdgcn_readfirstlane(rn);
+    ++done;
+  }
+  return done - 1;
+}
+
 template <bool LOSS, int NG2, int PL>
 __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SGPRS void raster2_fwd_kernel(
     const float4 *__restrict__ G, const int *__restrict__ goff, const int *__restrict__ lstart,
@@ -1215,7 +1297,10 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
 #else
     rcs[h] = (h == 0 || tid + h * NT < trec) ? Gn[min(tid + h * NT, S - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
-  const bool tbl = unit_m && nrows <= R2_MAX - 1 && lbase <= trec;     // block-uniform
+  // block-uniform: the table form (unit weights, at most 10 image rows under the block); a list longer than the table
+  // goes through it in chunks of trec records (scan2_parts_chunk)
+  const bool tblm = unit_m && nrows <= R2_MAX - 1;
+  const bool tbl = tblm && lbase <= trec, chunked = tblm && !tbl;
   // merge / write-out items: item e = it * NT + tid is tile pixel e / 4 (= 2 x pair-lane + row of the pair); its lane
   // sub4 = e % 4 takes the channel chunks sub4 and sub4 + 4 (channels 4 sub4 .. and 16 + 4 sub4 ..): four lanes per
   // pixel, ONE item per thread at 1 024 threads - the per-item fixed cost (pixel decode, list bounds, addresses) of
@@ -1244,14 +1329,15 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
     }
   }
   SMPLR_TL_STAMP(1);
-  if (tbl) {
+  // the table of the `cnt` records in rcs (thread i: records i, i + NT, ...)
+  auto build_table = [&](int cnt) {
     float *tab = reinterpret_cast<float *>(sTab);
     const float fr0 = (float)row0;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int i = tid + h * NT;
       const float4 rcd = rcs[h];
-      if (i < lbase) {
+      if (i < cnt) {
         float *dst = tab + ((i >> 2) * Rb) * 4 + (i & 3);
         dst[0] = rcd.x;
 #pragma unroll
@@ -1263,7 +1349,8 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
         }
       }
     }
-  }
+  };
+  if (tblm) build_table(min(lbase, trec));
   SMPLR_TL_STAMP(2);
   __syncthreads();
   SMPLR_TL_STAMP(3);
@@ -1296,7 +1383,30 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
       else if (Rb == 7) ndone = scan2_parts<7, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
       else if (Rb == 9) ndone = scan2_parts<9, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
       else ndone = scan2_parts<11, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA);
+    } else if (chunked) {
+      for (int c0 = 0;;) {
+        const int c1 = min(c0 + trec, lbase);
+        const bool last = c1 == lbase;
+        int nd;
+        if (Rb == 5) nd = scan2_parts_chunk<5, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA, c0, c1, last);
+        else if (Rb == 7) nd = scan2_parts_chunk<7, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA, c0, c1, last);
+        else if (Rb == 9) nd = scan2_parts_chunk<9, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA, c0, c1, last);
+        else nd = scan2_parts_chunk<11, NG2>(tb, offv, ordv, &sCtr[pw], g, P, lane == 0, va, fc2, myS, myA, c0, c1, last);
+        ndone += nd;
+        if (last) break;
+        c0 = c1;
+        // the next chunk's records (asked for here, not before the scan: eight registers the scan would have to hold
+        // took the kernel past its 64 and into scratch), under the wait for the block's slowest wave
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          rcs[h] = (h == 0 || tid + h * NT < trec) ? Gn[min(c0 + tid + h * NT, S - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();                                     // every wave is done with the table and with the draw counter
+        if (tid < PW) sCtr[tid] = R2_STATIC * NG2;
+        build_table(min(lbase - c0, trec));
+        __syncthreads();
+      }
     } else {
+      // (weights other than 1, or more than 10 image rows under the block)
       // the global record list by scalar loads, one record at a time (strict '<': the first arg-min in list order)
       const float fr0 = (float)(2 * Q), fr1 = fr0 + 1.0f;
       for (int r = g; r < P; r += NG2) {                   // (no balancing here)
@@ -3020,6 +3130,30 @@ int smplr_seg_raster_timed(int B, int W, int P, int K, const void *workspace, co
   SMPLR_REQUIRE(kernel_ms != nullptr, "smplr_seg_raster_timed: null kernel_ms");
   return smplr::seg_raster_impl("smplr_seg_raster_timed", B, W, P, K, workspace, rec, seg, arg, stream, smplr::LossOut{},
                                 kernel_ms);
+}
+
+int smplr_seg_raster_plan(int B, int W, int P, int K, int32_t *info, int32_t *tile_records) {
+  using namespace smplr;
+  if (B <= 0 || W <= 0 || W > 160 || P < 1 || P > 31 || K <= 0 || K > BIN_T * IPT_MAX) return 0;
+  static const int shape_env = getenv("SMPLR_RASTER_SHAPE") ? atoi(getenv("SMPLR_RASTER_SHAPE")) : 0;
+  const int shape = shape_env ? shape_env : raster2_shape(B, W, K);
+  const int pl = shape == 2 ? 64 : PLN, ng = shape == 2 ? 10 : shape == 3 ? 4 : 8;
+  const int ar = pl == 64 ? 6144 : ARENA;                  // raster2_fwd_kernel's AR
+  const int nq = (W + 1) / 2, nl = nq * W, nt = (nl + pl - 1) / pl;
+  int tmax = 0, tmin = 1 << 30, tall = 0;
+  for (int t = 0; t < nt; ++t) {                           // the kernel's own row count per tile
+    const int Qf = std::min(t * pl, nl - 1) / W, Ql = std::min(t * pl + pl - 1, nl - 1) / W;
+    const int nrows = 2 * (Ql - Qf + 1);
+    const int Rb = nrows <= 4 ? 5 : nrows <= 6 ? 7 : nrows <= 8 ? 9 : 11;
+    const int tr = nrows <= R2_MAX - 1 ? trec_of(ar, Rb) : 0;
+    if (tile_records) tile_records[t] = tr;
+    if (tr) { tmax = std::max(tmax, tr); tmin = std::min(tmin, tr); } else tall = 1;
+  }
+  if (info) {
+    info[0] = pl; info[1] = ng; info[2] = nt; info[3] = goff_stride(P);
+    info[4] = tmax; info[5] = tmin == (1 << 30) ? 0 : tmin; info[6] = tall; info[7] = 0;
+  }
+  return nt;
 }
 
 int smplr_seg_raster_ex(int B, int W, int P, int K, const void *workspace, const float *rec, const int32_t *labels,

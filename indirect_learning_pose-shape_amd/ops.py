@@ -471,6 +471,31 @@ def _seg_bwd(dseg, arg, rec, VP, W, pt: PartTable, merge=True, deterministic=Fal
     return dproj if merge else (ws, int(lib.smplr_seg_bwd_nsplit(B, W)))
 
 
+def raster_plan(rec, W, pt: PartTable):
+    """How the rasteriser ran (or will run) the batch whose record lists are `rec` - host arithmetic on the list headers
+    and smplr_seg_raster_plan; synchronises (a diagnostic for bench.py and the tests, never on the product path).
+    -> dict: far_records (B,) = each mesh's far-reaching list, padded per part; tile_records (tiles,) = what one pass
+    over a tile's LDS table takes (0: the tile walks the list with scalar loads); passes (B, tiles); blocks,
+    blocks_multi_pass, blocks_scalar_walk, passes_max; pair_lanes, part_ranges."""
+    import ctypes
+    lib = _lib.load()
+    B = rec.shape[0]
+    info = (ctypes.c_int32 * 8)()
+    nt = lib.smplr_seg_raster_plan(B, W, pt.P, pt.K, info, None)
+    if nt <= 0:
+        raise RuntimeError("smplr_seg_raster_plan: bad sizes B=%d W=%d P=%d K=%d" % (B, W, pt.P, pt.K))
+    tiles = (ctypes.c_int32 * nt)()
+    lib.smplr_seg_raster_plan(B, W, pt.P, pt.K, info, tiles)
+    head = rec[:, -1, :].contiguous().view(torch.int32).cpu().numpy()
+    far, nonunit = head[:, 2].astype(np.int64), head[:, 1] != 0
+    trec = np.asarray(list(tiles), np.int64)
+    walk = (trec[None, :] == 0) | nonunit[:, None]                                 # (B, tiles)
+    passes = np.where(walk, 0, np.maximum(1, -(-far[:, None] // np.maximum(trec[None, :], 1))))
+    return {"far_records": far, "tile_records": trec, "passes": passes, "blocks": int(B * nt),
+            "blocks_multi_pass": int((passes > 1).sum()), "blocks_scalar_walk": int(walk.sum()),
+            "passes_max": int(passes.max()) if passes.size else 0, "pair_lanes": int(info[0]), "part_ranges": int(info[1])}
+
+
 def argmin_vertices(arg, rec):
     """(B,W,W,31) int64 vertex positions of the maximising vertices (-1 = none) from arg/rec."""
     slots = arg[..., 1:].to(torch.int64)

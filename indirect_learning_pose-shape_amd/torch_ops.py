@@ -43,7 +43,8 @@ _ns = None
 
 
 def available() -> bool:
-    return os.path.exists(LIB_PATH) and os.environ.get("SMPLR_TORCH_OPS", "1") != "0"
+    # (not beside another build of the C-ABI library: this layer links the product one)
+    return os.path.exists(LIB_PATH) and os.environ.get("SMPLR_TORCH_OPS", "1") != "0" and not _lib.LIB_OVERRIDE
 
 
 def load():

@@ -28,7 +28,7 @@ def _ensure_built():
 
     # (read in a child process: a CDLL() here would pin the stale mapping and the load after the rebuild would get it back)
     if _lib.library_build_id() != _lib.source_build_id():
-        subprocess.run(["make", "-C", csrc, "-B", "-j4"], check=True, stdout=subprocess.DEVNULL,
+        subprocess.run(["make", "-C", csrc, "-B", "-j4", "PYTHON=" + sys.executable], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.STDOUT)
 
 

@@ -37,7 +37,7 @@ def test_ctypes_table_matches_header():
     from ilps_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_functions()
     lib = _lib.load()
-    assert lib.smplr_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.smplr_abi_version() == _lib.ABI_VERSION == 7
     # argument errors are reported without touching the GPU
     rc = lib.smplr_visibility(None, 1, 6890, 0, 1, None, None)
     assert rc == -1 and b"grid_wh" in lib.smplr_last_error()
@@ -143,7 +143,7 @@ def test_torch_library_registers_the_declared_ops():
     for name, schema in torch_ops.SCHEMAS.items():
         op = getattr(ns, name)
         assert str(op.default._schema) == schema, (name, str(op.default._schema))
-    assert int(ns.abi_version()) == 6
+    assert int(ns.abi_version()) == 7
     m = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device="meta")
     proj = m(2, 6890, 3)
     assert ns.visibility(proj).shape == (2, 6890)

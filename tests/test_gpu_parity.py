@@ -571,7 +571,10 @@ def test_seg_generic_masks_and_odd_width(layer, part_tables, mask_kind):
 
 @pytest.mark.parametrize("W,nfar,unit", [(48, 300, True), (48, 300, False), (48, 780, False), (48, 950, True),
                                          (48, 1100, True), (32, 300, True), (32, 700, True), (64, 600, False),
-                                         (96, 500, True), (128, 400, False), (160, 300, True)])
+                                         (96, 500, True), (128, 400, False), (160, 300, True),
+                                         # lists longer than the LDS table: two to nine passes over it (round 5)
+                                         (48, 1500, True), (48, 3000, True), (64, 1600, True), (64, 3200, True),
+                                         (32, 2000, True), (24, 1200, True), (48, 6879, True)])
 def test_seg_record_list_regimes(layer, part_tables, W, nfar, unit):
     """The forward rasteriser picks its pair loop by the length of a mesh's far-reaching record list and by the
     weights: (v - row)^2 row tables in LDS (lists up to ~860 records at W = 48 with unit weights, ~690 otherwise,
@@ -584,18 +587,43 @@ def test_seg_record_list_regimes(layer, part_tables, W, nfar, unit):
     proj = proj.detach()
     rng = np.random.default_rng(nfar + W)
     m = np.full((2, 6890), 500.0)
+    ids, off = part_tables[1]
     for b in range(2):
-        idx = rng.choice(6890, size=nfar, replace=False)
+        idx = rng.choice(np.asarray(ids), size=nfar, replace=False)     # (vertices of the part table: all of them count)
         m[b, idx] = 1.0 if unit else rng.choice([0.5, 1.0, 3.0, 150.0], size=nfar)
     mask = t(m)
     seg, arg = projects_to_seg([proj, mask], W, return_argmin=True)
-    ids, off = part_tables[1]
     want, warg = o.projects_to_seg(proj.cpu().numpy().astype(np.float64), m, W, ids, off, return_argmin=True)
     got = seg.cpu().numpy()
     assert np.all(np.abs(got - want) <= SEG_RTOL * np.abs(want) + SEG_ATOL)
     ndiff, bad = argmin_disagreements(arg.cpu().numpy(), warg, want, proj.cpu().numpy(), m, W)
     assert bad == 0, "%d of %d arg-min disagreements are not near-ties" % (bad, ndiff)
     assert ndiff <= 64, "%d arg-min disagreements: near-ties are rare (a handful per mesh)" % ndiff
+
+
+@pytest.mark.parametrize("W,B,nfar,passes", [(48, 128, 500, 1), (48, 128, 900, 2), (48, 8, 1500, 2), (64, 128, 1500, 2),
+                                             (64, 16, 6879, 5)])
+def test_raster_plan_counts_the_passes(layer, part_tables, W, B, nfar, passes):
+    """`ops.raster_plan` (list headers + smplr_seg_raster_plan, include/smplraster.h): the far-reaching list length the
+    binning kernel reports per mesh equals the count from the mask (each part padded to 4), and the passes over the LDS
+    table follow from the tile's table size - 800 / 1 032 records at W = 48 in 128-lane blocks, 1 228 in 64-lane blocks,
+    1 444 at W = 64."""
+    from ilps_amd import ops
+    ids, off = part_tables[1]
+    pt = ops.get_part_table(1, dev(), 6890)
+    rng = np.random.default_rng(W + nfar)
+    proj = t(np.concatenate([rng.uniform(0, W, (B, 6890, 2)), rng.normal(0, 1, (B, 6890, 1))], axis=2))
+    m = np.full((B, 6890), 500.0)
+    for b in range(B):
+        m[b, rng.choice(np.asarray(ids), size=nfar, replace=False)] = 1.0
+    rec = ops._seg_fwd(proj, t(m), W, pt)[2]
+    pl = ops.raster_plan(rec, W, pt)
+    vis = m[:, np.asarray(ids)] == 1.0
+    want = sum((vis[:, off[p]:off[p + 1]].sum(1) + 3) // 4 * 4 for p in range(len(off) - 1))
+    assert np.array_equal(pl["far_records"], want)
+    assert pl["passes_max"] == passes and pl["blocks_scalar_walk"] == 0
+    assert pl["blocks"] == B * len(pl["tile_records"])
+    assert (pl["blocks_multi_pass"] > 0) == (passes > 1)
 
 
 @pytest.mark.parametrize("P,VP,W,B", [(1, 64, 24, 3), (5, 300, 40, 9), (17, 1000, 48, 2), (31, 500, 20, 11)])
