@@ -19,6 +19,7 @@ Extra objects in the line:
                   cores on a bounded sample (rank 0, N=1 only); a reported baseline, not the target
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -510,6 +511,33 @@ def launch_ranks(n, argv):
     return proc.returncode
 
 
+def _host_placement():
+    """Where this rank runs on the host: the devices it may see, the cores it may run on and their NUMA nodes - eight
+    graph-replaying ranks on a 16-core cgroup is the first thing that bends a scaling curve (VERDICT r04 #8)."""
+    out = {"HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"),
+           "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"), "pid": os.getpid()}
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        out["cpu_affinity"] = len(cpus)
+        out["cpu_first_last"] = [cpus[0], cpus[-1]] if cpus else None
+        nodes = set()
+        for nd in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+            try:
+                ids = set()
+                for part in open(os.path.join(nd, "cpulist")).read().strip().split(","):
+                    if part:
+                        a, _, b = part.partition("-")
+                        ids.update(range(int(a), int(b or a) + 1))
+                if ids & set(cpus):
+                    nodes.add(int(os.path.basename(nd)[4:]))
+            except (OSError, ValueError):
+                pass
+        out["numa_nodes"] = sorted(nodes) if nodes else None
+    except (AttributeError, OSError):
+        out["cpu_affinity"] = None
+    return out
+
+
 def _ranks_seen(dist, rank, world, dev, backend, own_ms):
     """Every rank's (rank, device index, device name, its OWN ms per step before the MAX reduction), gathered on all
     ranks: the N > 1 line shows that N distinct devices took part (`rccl_ranks_seen`) and how far apart they ran."""
@@ -519,6 +547,7 @@ def _ranks_seen(dist, rank, world, dev, backend, own_ms):
     else:
         mine = {"rank": rank, "device": "cpu", "name": "cpu (pid %d)" % os.getpid(),
                 "backend": backend if world > 1 else None, "ms_per_step": round(own_ms, 4)}
+    mine["host"] = _host_placement()
     if dist is None or world == 1:
         return [mine]
     got = [None] * world
@@ -552,7 +581,7 @@ def _timed_steps(fn, warm, steps, dist, dev, backend, sync):
     return _max_over_ranks(dist, time.perf_counter() - t0, dev, backend)
 
 
-def train_leg(args, rank, world, dev, dist, backend, model, W):
+def train_leg(args, rank, world, dev, dist, backend, model, W, per=None):
     """The data-parallel TRAIN step of BASELINE configs[3]/[4] (train.py:205-215,
     train_stage2_silhouette.py:226-234): ENet(256x256x3) + IEF + HIP decoder with both heads + softmax-focal loss +
     silhouette cross-entropy + Adam, `--train-batch` images per GPU, DistributedDataParallel over RCCL when world > 1
@@ -563,7 +592,7 @@ def train_leg(args, rank, world, dev, dist, backend, model, W):
       strong_global_G     the step at G / world images per GPU (G = --train-global-batch, 1024: the strong-scaling point)"""
     import contextlib
     from ilps_amd.training import SegTrainer
-    per = int(args.train_batch)
+    per = int(args.train_batch) if per is None else int(per)
     steps, warm = int(args.train_steps), 3
     sync = torch.cuda.synchronize
     torch.manual_seed(1234)                                  # same initial weights on every rank (DDP broadcasts anyway)
@@ -924,6 +953,14 @@ def main():
             tleg = {"error": "%s: %s" % (type(e).__name__, e)}
             sys.stderr.write("bench: train leg failed on rank %d: %s\n" % (rank, tleg["error"]))
 
+    # BASELINE configs[3] as written: the same train step at B = 256 on one GPU (VERDICT r04 missing #4)
+    tleg256 = None
+    if not args.no_train_leg and world == 1 and int(args.train_batch) != 256:
+        try:
+            tleg256 = train_leg(args, rank, world, dev, dist, backend, model, W, per=256)
+        except Exception as e:
+            tleg256 = {"error": "%s: %s" % (type(e).__name__, e)}
+
     line = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -940,7 +977,7 @@ def main():
             "warmup_actual": nwarm * gsteps,
             "ms_per_step_graph1": None if ms_graph1 is None else round(ms_graph1, 4),
             "rccl_ranks_seen": seen, "rank_ms_per_step": [d["ms_per_step"] for d in seen],
-            "train_step": tleg,
+            "train_step": tleg, "train_step_B256": tleg256,
             "config": {"workload": ("full decoder fwd+bwd (batch_smpl + projection + compute_mask + "
                                     "projects_to_seg), BASELINE configs[2]" if variant_note is None
                                     else "VARIANT --step %s (not the headline): %s" % (args.step, variant_note)),
@@ -981,7 +1018,10 @@ def main():
                     _v, _p, _m, sg_, _s, _j, _l = ops.DecoderFn.apply(xg, c32, 4, W, 1, pt, 64, True, False, 1)
                     sg_.backward(dseg)
                 step32()
-                t32 = graph_time_ms(step32, 5, torch.cuda.current_stream())
+                t32 = graph_time_ms(step32, 10, torch.cuda.current_stream())
+                # the strict-fp32 headline beside `value`: same step, same batch, ten steps per graph replay
+                line["value_f32"] = round(world * B / (t32 * 1e-3), 1)
+                line["ms_per_step_f32"] = round(t32, 4)
                 line["step_blend_gemm_f32"] = {"ms_per_step": round(t32, 4), "meshes_per_s": round(B / (t32 * 1e-3), 1),
                                                "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) blend GEMMs; the headline "
                                                        "uses bf16x3 (3 x 8 = 24 significant bits per operand)"}

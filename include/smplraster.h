@@ -40,6 +40,14 @@ extern "C" {
 
 int smplr_abi_version(void);
 const char *smplr_last_error(void);
+/* Test hooks for the per-device launch state (kernels that need more than 48 KB of dynamic LDS have their attribute
+ * raised once per (kernel, device); the reference's multi_gpu_model towers, train.py:205-210, share nothing of the kind).
+ *   smplr_debug_device_ordinal(n)  n >= 0: the library takes n for the current device's ordinal in that table from now on
+ *                                  (a one-GPU box can then walk the table as a second device would); n < 0: hipGetDevice()
+ *                                  again.  Returns the previous setting (-1 = real).
+ *   smplr_debug_lds_attr_sets()    how many times the attribute has been set so far.                              */
+int smplr_debug_device_ordinal(int fake_ordinal);
+int smplr_debug_lds_attr_sets(void);
 /* sha256 (64 hex digits) over the sources this library was built from - the .hip and .h files of csrc/ (sorted by
  * name) and this header, concatenated; the host side recomputes it from the files beside the library and refuses a stale
  * library (`_lib.load`).  No reference counterpart: the reference ships no compiled code.                      */

@@ -31,6 +31,8 @@ SIGNATURES = {
     "smplr_abi_version": (c_int, []),
     "smplr_last_error": (c_char_p, []),
     "smplr_build_id": (c_char_p, []),
+    "smplr_debug_device_ordinal": (c_int, [I]),
+    "smplr_debug_lds_attr_sets": (c_int, []),
     "smplr_coef_ld": (c_int, [I]),
     "smplr_coef3_bytes": (c_size_t, [I]),
     "smplr_pose_fwd": (c_int, [P, I, I, I, P, P, P, P, P, P, P, P, P, P]),

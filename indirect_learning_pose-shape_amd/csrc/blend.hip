@@ -286,15 +286,10 @@ int launch_blend_bwd_partials(const float *dv_posed, const float *blend_t, int B
   const BlendBwdGeom g = blend_bwd_geom(B, N3);
   const int grid = ((g.nslices + 7) / 8) * 8 * g.nmt;
   const size_t lds = (size_t)4 * 32 * BW_NO * sizeof(float);
-  // once per DEVICE, as in blend3.hip (the attribute belongs to the device's copy of the kernel: a process-wide flag
-  // left a second device's launch without its 112 KB of LDS)
-  static bool attr_set[64] = {};
-  int dev = 0;
-  SMPLR_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(blend_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  static LdsAttrMemo memo = {};                       // once per (kernel, device): common.h
+  {
+    int rc = ensure_lds_attr(reinterpret_cast<const void *>(blend_bwd_kernel), lds, &memo, "blend_bwd_kernel");
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(256), lds, st, dv_posed, blend_t, B, N3, g.cols_per_block,
                      g.nslices, g.nmt, part);

@@ -623,15 +623,10 @@ int smplr_pose_blend3_fwd(const float *x, int x_stride, int num_cam, int B, cons
   const size_t lds_gemm = (size_t)4 * 32 * FC_LD * sizeof(float);
   const size_t lds_pose = (PB_MPB * sizeof(PoseLds) + 15) / 16 * 16 + (size_t)PB_MPB * 224 * sizeof(float);
   const size_t lds = lds_gemm > lds_pose ? lds_gemm : lds_pose;
-  // once per DEVICE (the attribute belongs to the device's copy of the kernel; the flags only save the repeated
-  // call - setting it twice, also from two threads at once, is harmless)
-  static bool attr_set[64] = {};
-  int dev = 0;
-  SMPLR_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pose_blend3_fwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  static LdsAttrMemo memo = {};                       // once per (kernel, device): common.h
+  {
+    int rc = ensure_lds_attr(reinterpret_cast<const void *>(pose_blend3_fwd_kernel), lds, &memo, "pose_blend3_fwd_kernel");
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(pose_blend3_fwd_kernel, dim3(npose + ntiles * ngroups), dim3(512), lds, as_stream(stream), x, x_stride,
                      num_cam, B, J_template, J_dirs, parents, reinterpret_cast<const u32x4 *>(pk_fwd), v_template, N3,

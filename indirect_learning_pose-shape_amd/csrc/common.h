@@ -41,6 +41,13 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int WAVE = 64;
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device): the attribute belongs to the device's copy of
+// a kernel, so a process-wide flag leaves a second device's launch without its LDS (found in round 3).  A call site keeps
+// one LdsAttrMemo per kernel; the ordinal is hipGetDevice()'s - or, for the one-GPU test box, the fake one set through
+// smplr_debug_device_ordinal() (tests/test_gpu_baseline_sizes.py walks the table with it).  Returns 0 or a hipError_t.
+struct LdsAttrMemo { size_t set[64]; };
+int ensure_lds_attr(const void *fn, size_t lds, LdsAttrMemo *memo, const char *what);
+
 // Stores of tensors that nothing in the step reads again (verts, proj, mask, the scores): non-temporal, so that they
 // do not push the 54 MB of packed blend constants and the step's own intermediates out of the Infinity Cache
 // (the step moves 317 MB against its 256 MB): A/B on one box, default step 0.1298 / 0.1289 against 0.1307 / 0.1301 ms,

@@ -21,6 +21,32 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+static int g_fake_ordinal = -1;      // >= 0: what ensure_lds_attr takes for the current device (tests)
+static int g_lds_attr_sets = 0;      // hipFuncSetAttribute calls made through ensure_lds_attr
+
+int ensure_lds_attr(const void *fn, size_t lds, LdsAttrMemo *memo, const char *what) {
+  int dev = 0;
+  if (g_fake_ordinal >= 0) {
+    dev = g_fake_ordinal;
+  } else {
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+      set_error("%s: hipGetDevice failed: %s", what, hipGetErrorString(e));
+      return (int)e;
+    }
+  }
+  const bool known = dev >= 0 && dev < 64;
+  if (known && memo->set[dev] >= lds) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%zu B of LDS) failed: %s", what, lds, hipGetErrorString(e));
+    return (int)e;
+  }
+  ++g_lds_attr_sets;
+  if (known) memo->set[dev] = lds;
+  return 0;
+}
+
 // Given dR (gradient wrt the 9 entries of R) return dtheta.
 __device__ __forceinline__ void rodrigues_bwd(const float t[3], const float dR[9], float dt[3]) {
   const float e[3] = {t[0] + 1e-8f, t[1] + 1e-8f, t[2] + 1e-8f};
@@ -302,6 +328,13 @@ __global__ __launch_bounds__(PBW) void pose_bwd_kernel(
 extern "C" {
 
 int smplr_abi_version(void) { return SMPLR_ABI_VERSION; }
+
+int smplr_debug_device_ordinal(int fake) {
+  const int prev = smplr::g_fake_ordinal;
+  smplr::g_fake_ordinal = fake < 0 ? -1 : (fake < 64 ? fake : 63);
+  return prev;
+}
+int smplr_debug_lds_attr_sets(void) { return smplr::g_lds_attr_sets; }
 const char *smplr_last_error(void) { return smplr::g_err; }
 
 int smplr_coef_ld(int B) { return B > 0 ? (B + 31) / 32 * 32 : 0; }

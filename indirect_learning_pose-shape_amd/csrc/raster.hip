@@ -43,7 +43,8 @@ __host__ __device__ constexpr int goff_stride(int P) { return P + 2 + 32; }   //
 constexpr int BIN_Q0 = SMPLR_BIN_Q0;   // seg_bin_kernel<.., SKIN>: vertices per thread whose operands are requested before the first barrier
 
 constexpr int CH = SMPLR_CHUNK;      // 8: silhouette list padding
-static int set_lds_attr(const void *fn, size_t lds);
+template <auto Kernel>
+static int lds_attr(size_t lds);
 constexpr int RT = 256;              // pixels (threads) per silhouette raster block
 constexpr float X_ZERO = 104.0f;     // expf(-x) rounds to 0 in fp32 for x >= 104
 constexpr float M_LOCAL = 208.0f;    // m > 208 => 104/m < 0.5 px: only the nearest pixel centre
@@ -2871,15 +2872,13 @@ __global__ __launch_bounds__(1024) void silh_bwd_kernel(const float *__restrict_
   }
 }
 
-static int set_lds_attr(const void *fn, size_t lds) {
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
-      return (int)e;
-    }
-  }
-  return 0;
+// More than 48 KB of dynamic LDS needs the kernel's attribute raised - once per (kernel, device), common.h's memo (one per
+// instantiation: the kernel is the template argument)
+template <auto Kernel>
+static int lds_attr(size_t lds) {
+  static LdsAttrMemo memo = {};
+  if (lds <= 48 * 1024) return 0;
+  return ensure_lds_attr(reinterpret_cast<const void *>(Kernel), lds, &memo, "raster.hip");
 }
 
 struct SegWs {
@@ -2957,7 +2956,7 @@ static int seg_bin_impl(const char *fn, const float *proj, float *mask, bool fus
   const size_t lds = bl.total;
 #define SMPLR_BIN_LAUNCH(VIS_, STAGE_, SKIN_)                                                                 \
   {                                                                                                           \
-    int rc = set_lds_attr(reinterpret_cast<const void *>(seg_bin_kernel<VIS_, STAGE_, SKIN_>), lds);          \
+    int rc = lds_attr<&seg_bin_kernel<VIS_, STAGE_, SKIN_>>(lds);          \
     if (rc) return rc;                                                                                        \
     hipLaunchKernelGGL((seg_bin_kernel<VIS_, STAGE_, SKIN_>), dim3(B), dim3(BIN_T), lds, st, proj, mask,      \
                        part_pos, part_off, P, K, VP, W, S, G, goff, lstart, lrec, fuse_vis ? grid_wh : 1,     \
@@ -3211,8 +3210,8 @@ static int seg_bwd_impl(const char *fn, const float *dseg, LossIn li, const int1
   static const int pipe = getenv("SMPLR_SEGBWD_PIPE") ? atoi(getenv("SMPLR_SEGBWD_PIPE")) : 1;   // 0: the unpipelined row walk (A/B runs)
   if (deterministic) {
     const size_t lds = (size_t)SB_SLOTS * 2 * sizeof(unsigned long long);
-    int rc = with_loss ? set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true, true>), lds)
-                       : set_lds_attr(reinterpret_cast<const void *>(seg_bwd_kernel<true, false>), lds);
+    int rc = with_loss ? lds_attr<&seg_bwd_kernel<true, true>>(lds)
+                       : lds_attr<&seg_bwd_kernel<true, false>>(lds);
     if (rc) return rc;
     if (with_loss) SMPLR_SEGBWD_LAUNCH(true, true, lds);
     else SMPLR_SEGBWD_LAUNCH(true, false, lds);
@@ -3266,7 +3265,7 @@ int smplr_silh_fwd_hint(const float *proj, const float *hint, int B, int VP, int
   if (W + 2 * SM <= 64 && VP <= SF_T * IPT_MAX && silh_px_layout(VP, W).total <= 159 * 1024) {
     const SpxLds L = silh_px_layout(VP, W);
     const int nsplit = B >= 256 ? 1 : (B >= 128 ? 2 : 4);      // one workgroup per CU (256 CUs)
-    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_px_kernel), L.total);
+    int rc = lds_attr<&silh_px_kernel>(L.total);
     if (rc) return rc;
     hipLaunchKernelGGL(silh_px_kernel, dim3(B, nsplit), dim3(SF_T), L.total, st, proj, VP, W, L, silh, arg, hint);
     SMPLR_LAUNCH_CHECK("smplr_silh_fwd");
@@ -3276,11 +3275,11 @@ int smplr_silh_fwd_hint(const float *proj, const float *hint, int B, int VP, int
     const size_t lds = silh_fused_lds(VP, W);
     const int nsplit = B >= 256 ? 1 : (B >= 128 ? 2 : 4);      // one workgroup per CU (256 CUs)
     if (W + 2 * SM <= 64) {
-      int rc = set_lds_attr(reinterpret_cast<const void *>(silh_fused_kernel<true>), lds);
+      int rc = lds_attr<&silh_fused_kernel<true>>(lds);
       if (rc) return rc;
       hipLaunchKernelGGL(silh_fused_kernel<true>, dim3(B, nsplit), dim3(SF_T), lds, st, proj, VP, W, silh, arg);
     } else {
-      int rc = set_lds_attr(reinterpret_cast<const void *>(silh_fused_kernel<false>), lds);
+      int rc = lds_attr<&silh_fused_kernel<false>>(lds);
       if (rc) return rc;
       hipLaunchKernelGGL(silh_fused_kernel<false>, dim3(B, nsplit), dim3(SF_T), lds, st, proj, VP, W, silh, arg);
     }
@@ -3308,12 +3307,12 @@ int smplr_silh_bwd(const float *dsilh, const float *silh, const int32_t *arg, co
   const size_t lds = (size_t)per * 2 * (deterministic ? sizeof(unsigned long long) : sizeof(float));
   SMPLR_REQUIRE(lds <= 150 * 1024, "smplr_silh_bwd: VP=%d needs %zu B of LDS", VP, lds);
   if (deterministic) {
-    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel<true>), lds);
+    int rc = lds_attr<&silh_bwd_kernel<true>>(lds);
     if (rc) return rc;
     hipLaunchKernelGGL(silh_bwd_kernel<true>, dim3(B, nsplit), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj,
                        VP, W, dproj);
   } else {
-    int rc = set_lds_attr(reinterpret_cast<const void *>(silh_bwd_kernel<false>), lds);
+    int rc = lds_attr<&silh_bwd_kernel<false>>(lds);
     if (rc) return rc;
     hipLaunchKernelGGL(silh_bwd_kernel<false>, dim3(B, nsplit), dim3(1024), lds, as_stream(stream), dsilh, silh, arg, proj,
                        VP, W, dproj);

@@ -16,7 +16,9 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
+#include <initializer_list>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/smplraster.h"
@@ -46,6 +48,14 @@ const Tensor &dev_typed(const Tensor &t, at::ScalarType ty, const char *name) {
   TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
   return t;
 }
+// every operand of a launch on the device the guard selects (a CPU constant or a tensor of another GPU would be a page
+// fault inside the kernel, not an error)
+void same_device(const Tensor &ref, std::initializer_list<std::pair<const char *, const Tensor *>> ts) {
+  for (const auto &nt : ts) {
+    if (!nt.second->defined() || nt.second->numel() == 0) continue;
+    TORCH_CHECK(nt.second->device() == ref.device(), nt.first, " lives on ", nt.second->device(), ", the launch runs on ", ref.device());
+  }
+}
 const float *fp(const Tensor &t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
 float *fpm(Tensor &t) { return t.defined() && t.numel() ? t.data_ptr<float>() : nullptr; }
 Tensor bytes(size_t n, const Tensor &like) {
@@ -71,6 +81,7 @@ Tensor project_fwd(const Tensor &verts, const Tensor &cam, int64_t vs) {
   dev_f32(cam, "cam");
   TORCH_CHECK(verts.dim() == 3 && verts.size(2) == 3 && cam.dim() == 2 && cam.size(0) == verts.size(0) && cam.size(1) >= 4 && vs >= 1,
               "project_fwd: verts (B,V,3), cam (B,>=4), vertex_sampling >= 1");
+  same_device(verts, {{"cam", &cam}});
   DeviceGuard g(verts.device());
   const int64_t B = verts.size(0), V = verts.size(1), VP = (V + vs - 1) / vs;
   Tensor proj = f32({B, VP, 3}, verts);
@@ -85,6 +96,9 @@ std::tuple<Tensor, Tensor> project_bwd(const Tensor &dproj, const Tensor &verts,
   dev_f32(dproj, "dproj");
   dev_f32(verts, "verts");
   dev_f32(cam, "cam");
+  TORCH_CHECK(verts.dim() == 3 && verts.size(2) == 3 && cam.dim() == 2 && cam.size(0) == verts.size(0) && cam.size(1) >= 4 && vs >= 1,
+              "project_bwd: verts (B,V,3), cam (B,>=4), vertex_sampling >= 1");
+  same_device(verts, {{"dproj", &dproj}, {"cam", &cam}});
   DeviceGuard g(verts.device());
   const int64_t B = verts.size(0), V = verts.size(1);
   TORCH_CHECK(dproj.dim() == 3 && dproj.size(0) == B && dproj.size(1) == (V + vs - 1) / vs && dproj.size(2) == 3, "dproj must be (B, VP, 3)");
@@ -113,6 +127,8 @@ std::tuple<Tensor, Tensor, Tensor> seg_fwd(const Tensor &proj, const Tensor &mas
   const PartDims d = part_dims(part_pos, part_off);
   TORCH_CHECK(proj.dim() == 3 && proj.size(2) == 3 && mask.dim() == 2 && mask.size(0) == proj.size(0) && mask.size(1) == proj.size(1),
               "seg_fwd: proj (B,VP,3), mask (B,VP)");
+  TORCH_CHECK(W > 0 && W <= 160, "seg_fwd: 0 < W <= 160");
+  same_device(proj, {{"mask", &mask}, {"part_pos", &part_pos}, {"part_off", &part_off}});
   DeviceGuard g(proj.device());
   const int64_t B = proj.size(0), VP = proj.size(1);
   Tensor seg = f32({B, W, W, d.P + 1}, proj), arg = at::empty({B, W, W, 32}, proj.options().dtype(at::kShort));
@@ -134,8 +150,14 @@ Tensor seg_bwd(const Tensor &dseg, const Tensor &arg, const Tensor &rec, int64_t
   dev_typed(arg, at::kShort, "arg");
   dev_f32(rec, "rec");
   TORCH_CHECK(dseg.dim() == 4 && dseg.size(1) == dseg.size(2) && dseg.size(3) == P + 1, "dseg must be (B,W,W,P+1)");
-  DeviceGuard g(dseg.device());
   const int64_t B = dseg.size(0), W = dseg.size(1);
+  TORCH_CHECK(P >= 1 && P <= 31 && K >= 1 && VP >= 1, "seg_bwd: 1 <= P <= 31, K >= 1, VP >= 1");
+  TORCH_CHECK(arg.dim() == 4 && arg.size(0) == B && arg.size(1) == W && arg.size(2) == W && arg.size(3) == 32,
+              "arg must be (B,W,W,32) int16 as seg_fwd returned it");
+  TORCH_CHECK(rec.dim() == 3 && rec.size(0) == B && rec.size(1) == smplr_seg_slots((int)P, (int)K) && rec.size(2) == 4,
+              "rec must be (B, smplr_seg_slots(P,K), 4) as seg_fwd returned it for this part table");
+  same_device(dseg, {{"arg", &arg}, {"rec", &rec}});
+  DeviceGuard g(dseg.device());
   Tensor dproj = f32({B, VP, 3}, dseg);
   Tensor ws = bytes(smplr_seg_bwd_workspace((int)B, (int)W), dseg);
   ok(smplr_seg_bwd(fp(dseg), arg.data_ptr<int16_t>(), fp(rec), (int)B, (int)VP, (int)W, (int)P, (int)K, fpm(dproj),
@@ -150,6 +172,7 @@ Tensor seg_bwd_meta(const Tensor &dseg, const Tensor &, const Tensor &, int64_t 
 std::tuple<Tensor, Tensor> silh_fwd(const Tensor &proj, int64_t W) {
   dev_f32(proj, "proj");
   TORCH_CHECK(proj.dim() == 3 && proj.size(2) == 3, "proj must be (B, VP, 3)");
+  TORCH_CHECK(W > 0, "silh_fwd: W > 0");
   DeviceGuard g(proj.device());
   const int64_t B = proj.size(0), VP = proj.size(1);
   Tensor silh = f32({B, W, W, 2}, proj), sarg = at::empty({B, W, W}, proj.options().dtype(at::kInt));
@@ -166,6 +189,13 @@ Tensor silh_bwd(const Tensor &dsilh, const Tensor &silh, const Tensor &sarg, con
   dev_f32(silh, "silh");
   dev_typed(sarg, at::kInt, "arg");
   dev_f32(proj, "proj");
+  TORCH_CHECK(proj.dim() == 3 && proj.size(2) == 3, "proj must be (B, VP, 3)");
+  TORCH_CHECK(silh.dim() == 4 && silh.size(0) == proj.size(0) && silh.size(1) == silh.size(2) && silh.size(3) == 2,
+              "silh must be (B,W,W,2) as silh_fwd returned it");
+  TORCH_CHECK(dsilh.sizes() == silh.sizes(), "dsilh must have silh's shape");
+  TORCH_CHECK(sarg.dim() == 3 && sarg.size(0) == silh.size(0) && sarg.size(1) == silh.size(1) && sarg.size(2) == silh.size(2),
+              "arg must be (B,W,W) int32 as silh_fwd returned it");
+  same_device(proj, {{"dsilh", &dsilh}, {"silh", &silh}, {"arg", &sarg}});
   DeviceGuard g(proj.device());
   const int64_t B = proj.size(0), VP = proj.size(1), W = silh.size(1);
   Tensor dproj = f32({B, VP, 3}, proj);
@@ -193,6 +223,24 @@ Consts unpack(const std::vector<Tensor> &c) {
   TORCH_CHECK(c[4].defined() && c[4].numel() > 0 && c[4].is_cuda(), "blend3_fwd missing: upload the constants with SMPLR_BLEND_GEMM=bf16x3");
   dev_f32(c[6], "lbs_weights");
   TORCH_CHECK(c[3].numel() % 3 == 0, "v_template must hold 3V floats");
+  const int64_t V_ = c[3].numel() / 3;
+  TORCH_CHECK(c[0].numel() == 72 && c[1].numel() == 720 && c[2].numel() == 24, "J_template (24,3), J_dirs (24,3,10), parents (24)");
+  TORCH_CHECK(c[6].numel() == V_ * 24, "lbs_weights must be (V,24)");
+  TORCH_CHECK(c[4].is_contiguous() && (size_t)c[4].nbytes() >= smplr_blend3_fwd_bytes((int)(3 * V_)),
+              "blend3_fwd is smaller than smplr_blend3_fwd_bytes(3V)");
+  if (c[5].defined() && c[5].numel() > 0)
+    TORCH_CHECK(c[5].is_cuda() && c[5].is_contiguous() && (size_t)c[5].nbytes() >= smplr_blend3_bwd_bytes((int)(3 * V_)),
+                "blend3_bwd must be a contiguous device buffer of smplr_blend3_bwd_bytes(3V)");
+  if (c[7].defined() && c[7].numel() > 0) {
+    dev_f32(c[7], "lbs_top4");
+    TORCH_CHECK(c[7].numel() == V_ * 8, "lbs_top4 must be (V,8)");
+  }
+  if (c[8].defined() && c[8].numel() > 0) {
+    dev_f32(c[8], "blend_t");
+    TORCH_CHECK(c[8].numel() == 3 * V_ * 224, "blend_t must be (3V,224)");
+  }
+  same_device(c[3], {{"J_template", &c[0]}, {"J_dirs", &c[1]}, {"parents", &c[2]}, {"blend3_fwd", &c[4]}, {"blend3_bwd", &c[5]},
+                     {"lbs_weights", &c[6]}, {"lbs_top4", &c[7]}, {"blend_t", &c[8]}});
   return Consts{c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], (int)(c[3].numel() / 3)};
 }
 // -> verts (B,V,3), v_posed (B,V,3), A (B,24,12), Rs (B,24,9), J (B,24,3), J_transformed (B,24,3)
@@ -200,6 +248,7 @@ std::vector<Tensor> smpl_fwd(const Tensor &x, const std::vector<Tensor> &consts,
   dev_f32(x, "x");
   const Consts c = unpack(consts);
   TORCH_CHECK(x.dim() == 2 && x.size(1) == num_cam + 82, "x must be (B, num_cam + 82)");
+  same_device(x, {{"consts", &c.vt}});
   DeviceGuard g(x.device());
   const int64_t B = x.size(0);
   Tensor Rs = f32({B, 24, 9}, x), J = f32({B, 24, 3}, x), A = f32({B, 24, 12}, x), Jt = f32({B, 24, 3}, x);
@@ -229,8 +278,18 @@ Tensor smpl_bwd(const c10::optional<Tensor> &dverts, const c10::optional<Tensor>
   if (dJt) dev_f32(*dJt, "dJ_transformed");
   dev_f32(Rs, "Rs"); dev_f32(J, "J"); dev_f32(A, "A"); dev_f32(v_posed, "v_posed");
   TORCH_CHECK(c.b3b.defined() && c.b3b.numel() > 0, "blend3_bwd missing");
-  DeviceGuard g(x.device());
+  TORCH_CHECK(x.dim() == 2 && x.size(1) == num_cam + 82 && vs >= 1, "x must be (B, num_cam + 82), vertex_sampling >= 1");
   const int64_t B = x.size(0);
+  TORCH_CHECK(Rs.numel() == B * 216 && J.numel() == B * 72 && A.numel() == B * 288 && v_posed.numel() == B * 3 * c.V,
+              "Rs (B,24,9), J (B,24,3), A (B,24,12), v_posed (B,V,3) as smpl_fwd returned them");
+  if (dverts) TORCH_CHECK(dverts->numel() == B * 3 * c.V, "dverts must be (B,V,3)");
+  if (dproj) TORCH_CHECK(dproj->numel() == B * 3 * ((c.V + vs - 1) / vs), "dproj must be (B,VP,3)");
+  if (dJt) TORCH_CHECK(dJt->numel() == B * 72, "dJ_transformed must be (B,24,3)");
+  same_device(x, {{"consts", &c.vt}, {"Rs", &Rs}, {"J", &J}, {"A", &A}, {"v_posed", &v_posed}});
+  if (dverts) same_device(x, {{"dverts", &*dverts}});
+  if (dproj) same_device(x, {{"dproj", &*dproj}});
+  if (dJt) same_device(x, {{"dJ_transformed", &*dJt}});
+  DeviceGuard g(x.device());
   Tensor dx = f32({B, x.size(1)}, x);
   Tensor ws = bytes(smplr_smpl_bwd_workspace((int)B, c.V), x);
   ok(smplr_smpl_bwd(dverts ? fp(*dverts) : nullptr, dproj ? fp(*dproj) : nullptr, nullptr, nullptr, 0, dJt ? fp(*dJt) : nullptr,
@@ -255,6 +314,7 @@ std::vector<Tensor> decoder_fwd(const Tensor &x, const std::vector<Tensor> &cons
   const PartDims d = part_dims(part_pos, part_off);
   TORCH_CHECK(x.dim() == 2 && x.size(1) == num_cam + 82, "x must be (B, num_cam + 82)");
   TORCH_CHECK(grid_wh > 0 && grid_wh <= 128 && W > 0 && W <= 160, "decoder_fwd: 0 < grid_wh <= 128, 0 < W <= 160");
+  same_device(x, {{"consts", &c.vt}, {"part_pos", &part_pos}, {"part_off", &part_off}});
   DeviceGuard g(x.device());
   const int64_t B = x.size(0), V = c.V;
   Tensor Rs = f32({B, 24, 9}, x), J = f32({B, 24, 3}, x), A = f32({B, 24, 12}, x), Jt = f32({B, 24, 3}, x);

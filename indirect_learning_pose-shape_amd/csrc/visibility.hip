@@ -65,8 +65,9 @@ extern "C" int smplr_visibility(const float *proj, int B, int VP, int grid_wh, i
   const size_t lds = (size_t)grid_wh * grid_wh * 8 + (size_t)((VP + 31) / 32) * 4;
   SMPLR_REQUIRE(lds <= 150 * 1024, "smplr_visibility: grid + flags need %zu B of LDS (max 153600)", lds);
   if (lds > 48 * 1024) {
-    SMPLR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(visibility_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static LdsAttrMemo memo = {};                     // once per (kernel, device): common.h
+    int rc = ensure_lds_attr(reinterpret_cast<const void *>(visibility_kernel), lds, &memo, "visibility_kernel");
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(visibility_kernel, dim3(B), dim3(1024), lds, as_stream(stream), proj, VP, grid_wh,
                      ref_compat, mask);

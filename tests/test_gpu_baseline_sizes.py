@@ -266,6 +266,44 @@ def test_ops_follow_their_operands_device(smpl_model, blend_gemm, monkeypatch):
     grad_close(res[1][2].numpy(), res[0][2].numpy(), 1e-5, "dx cuda:1 vs cuda:0")
 
 
+@pytest.mark.parametrize("blend_gemm", ["bf16x3", "f32"])
+def test_lds_attribute_table_follows_the_device_ordinal(smpl_model, blend_gemm, monkeypatch):
+    """The per-(kernel, device) table of raised LDS limits on a ONE-GPU box (the two-device test above
+    is skipped here): a step sets each large-LDS kernel's attribute once, a second step sets nothing, and after
+    smplr_debug_device_ordinal(1) - the library now files the current device under ordinal 1, as a second GPU's
+    first launches would be - the same step sets every one of them again and computes the same bits."""
+    from ilps_amd import _lib
+    from ilps_amd.decoder import SMPLDecoder
+    monkeypatch.setenv("SMPLR_BLEND_GEMM", blend_gemm)
+    lib = _lib.load()
+    W, B = 48, 3
+    x = t(make_x(B, W, seed=5))
+    g = t(np.random.default_rng(5).normal(0, 1, (B, W, W, 32)))
+    gs = t(np.random.default_rng(6).normal(0, 1, (B, W, W, 2)))
+
+    def step():
+        dec = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=True, deterministic=True)
+        xg = x.clone().requires_grad_(True)
+        out = dec(xg)
+        torch.autograd.backward([out["seg"], out["silhouette"]], [g, gs])
+        torch.cuda.synchronize()
+        return out["seg"].detach().clone(), out["silhouette"].detach().clone(), xg.grad.clone()
+    prev = lib.smplr_debug_device_ordinal(7)            # an ordinal nothing has run under yet
+    try:
+        n0 = lib.smplr_debug_lds_attr_sets()
+        a = step()
+        n1 = lib.smplr_debug_lds_attr_sets()
+        step()
+        assert lib.smplr_debug_lds_attr_sets() == n1, "a second step on the same device set attributes again"
+        assert n1 - n0 >= 3, "the step has at least three kernels above 48 KB of LDS (GEMM, binning, silhouette): %d" % (n1 - n0)
+        lib.smplr_debug_device_ordinal(8)
+        b = step()
+        assert lib.smplr_debug_lds_attr_sets() - n1 == n1 - n0, "a new device ordinal must set every attribute again"
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+    finally:
+        lib.smplr_debug_device_ordinal(prev)
+
+
 @pytest.mark.parametrize("with_silh", [False, True])
 def test_deterministic_backward_is_bit_reproducible_B128(smpl_model, with_silh):
     """SMPLDecoder(deterministic=True) at B = 128 (race row: the reference's ops are pure functions):

@@ -68,3 +68,35 @@ def test_single_ops_equal_the_ctypes_calls(smpl_model, part_tables):
     dx2 = torch.empty_like(x)
     ops._smpl_bwd(x, 4, c, Rs2, J2, A2, vp2, dv, None, None, 1, out=dx2)
     assert torch.equal(dx, dx2) and bool(torch.isfinite(dx).all())
+
+
+def test_mismatched_operands_raise_instead_of_faulting(smpl_model):
+    """The ops hand caller-supplied sizes to the launchers, so every shape and device is checked first: a
+    wrong `arg` / `rec` / `silh`, a part table of another size, a CPU constant - each a RuntimeError, never a launch."""
+    ops, ns, dev, c, pt, x = _setup(smpl_model, 2, 48, 9)
+    verts, v_posed, A, Rs, J, Jt = ns.smpl_fwd(x, c.as_list())
+    proj = ns.project_fwd(verts, x)
+    mask = ns.visibility(proj)
+    seg, arg, rec = ns.seg_fwd(proj, mask, pt.part_pos, pt.part_off, 48)
+    g = torch.randn_like(seg)
+    bad = [
+        lambda: ns.seg_bwd(g, arg[:, :24].contiguous(), rec, pt.VP, pt.P, pt.K, False),          # arg of another image size
+        lambda: ns.seg_bwd(g, arg, rec[:, :100].contiguous(), pt.VP, pt.P, pt.K, False),          # rec shorter than S(P, K)
+        lambda: ns.seg_bwd(g, arg, rec, pt.VP, pt.P, pt.K - 7, False),                            # K of another part table
+        lambda: ns.seg_bwd(g, arg.cpu(), rec, pt.VP, pt.P, pt.K, False),
+        lambda: ns.seg_fwd(proj, mask, pt.part_pos.cpu(), pt.part_off, 48),
+        lambda: ns.project_bwd(proj, verts, x[:, :3].contiguous()),                               # cam narrower than 4
+        lambda: ns.smpl_bwd(verts, None, None, x, c.as_list(), Rs[:1].contiguous(), J, A, v_posed),
+        lambda: ns.smpl_bwd(verts, None, None, x, [t.cpu() if i == 6 else t for i, t in enumerate(c.as_list())], Rs, J, A, v_posed),
+        lambda: ns.decoder_fwd(x, [t.cpu() if i == 7 else t for i, t in enumerate(c.as_list())], pt.part_pos, pt.part_off, 48),
+    ]
+    silh, sarg = ns.silh_fwd(proj, 48)
+    bad += [lambda: ns.silh_bwd(torch.randn(2, 24, 24, 2, device=dev), silh, sarg, proj, False),
+            lambda: ns.silh_bwd(torch.randn_like(silh), silh, sarg[:, :24].contiguous(), proj, False),
+            lambda: ns.silh_bwd(torch.randn_like(silh), silh, sarg, proj.cpu(), False)]
+    for i, f in enumerate(bad):
+        with pytest.raises(RuntimeError):
+            f()
+            pytest.fail("case %d did not raise" % i)
+    torch.cuda.synchronize()                                           # nothing was launched, nothing faulted
+    assert torch.isfinite(ns.seg_bwd(g, arg, rec, pt.VP, pt.P, pt.K, False)).all()
