@@ -136,7 +136,8 @@ inline int seg_bwd_rows(int B, int W) {
 struct SegGrad { const float *part; const int16_t *vslot; int nsplit; };
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
-                             int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st);
+                             int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st,
+                             int *nblk_out /* partial blocks per mesh it wrote: pose_bwd / the reduce sum that many */);
 
 // Linear-blend skinning of one vertex from its <= 4 (weight, joint) pairs against the mesh's 24 x 12 joint matrix in
 // LDS (sAj: 72 float4), then the orthographic projection.  One definition for the two kernels that must

@@ -408,9 +408,10 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *seg_par
   float *skin_part = reinterpret_cast<float *>(base + align256((size_t)B * V * 3 * sizeof(float)));
   float *blend_part = reinterpret_cast<float *>(reinterpret_cast<char *>(skin_part) +
                                                 align256((size_t)B * skin_bwd_nblk(V) * 292 * sizeof(float)));
+  int skin_nblk = 0;
   int rc = launch_skin_bwd_partials(dverts, dproj, SegGrad{seg_part, seg_vslot, seg_nsplit}, v_posed, lbs_weights,
                                     lbs_top4, A, has_proj ? x : nullptr, x_stride, B, V, vertex_sampling, dv_posed,
-                                    skin_part, st);
+                                    skin_part, st, &skin_nblk);
   if (rc) return rc;
   int nslices, nmt;
   if (blend3_bwd) {                              // bf16x3 operands (blend3.hip); else the fp32 matrix-core GEMM
@@ -427,7 +428,7 @@ int smplr_smpl_bwd(const float *dverts, const float *dproj, const float *seg_par
   if (rc) return rc;
   hipLaunchKernelGGL(pose_bwd_kernel, dim3(B), dim3(PBW), 0, st, x, x_stride, num_cam, B,
                      J_dirs, parents, Rs, J, A, (const float *)nullptr, (const float *)nullptr, dJ_transformed,
-                     (const float *)nullptr, dx, skin_part, skin_bwd_nblk(V), blend_part, nslices, nmt,
+                     (const float *)nullptr, dx, skin_part, skin_nblk, blend_part, nslices, nmt,
                      has_proj ? 1 : 0);
   SMPLR_LAUNCH_CHECK("smplr_smpl_bwd(pose)");
   return 0;

@@ -358,12 +358,206 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restric
   if (tid < 4) dcam[(size_t)n * 4 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The skinning backward over RECORDS instead of vertices (round 5).  When the only gradient that reaches the vertices is
+// the part rasteriser's (seg_bwd's slot sums; no d verts, no merged d proj: the decoder's training step), a vertex without
+// a record - hidden and further than 0.208 px from every pixel centre: 78 % of them - has g = 0: its dv_posed row is
+// zero and it adds nothing to dA or the camera sums, yet skin_bwd_kernel loads its weights and v_posed row, blends its T
+// and feeds it to the dA product like any other.  Here a workgroup takes 1 024 consecutive vertices, zero-fills the
+// dv_posed rows of those without a record as it reads their vslot, compacts the others ((vertex, slot) in vertex order:
+// ballot + prefix sums, no atomics, so the order - and with it every sum - is the same on every launch) and runs
+// skin_bwd_kernel's arithmetic on the compact list alone: the slot sums straight by slot (one hop instead of vertex ->
+// slot -> sums), T rows 0 and 1 (row 2 multiplies g_z = 0), the dA tile on the matrix cores with the weights gathered
+// per record.  dv_posed is bit for bit skin_bwd_kernel's; dA and the camera sums add the same terms in another order.
+constexpr int SKR_T = 256;         // threads
+constexpr int SKR_VPT = 4;         // vertices per thread in the compaction pass
+constexpr int SKR_CHUNK = SKR_T * SKR_VPT;
+
+__global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
+    const float *__restrict__ v_posed, const float *__restrict__ lbs, const float *__restrict__ top4,
+    const float *__restrict__ A, const float *__restrict__ cam, int x_stride, int B, int V, int vs, int VP,
+    float *__restrict__ dv_posed, float *__restrict__ part, const float *__restrict__ seg_part,
+    const short *__restrict__ seg_vslot, int seg_nsplit) {
+  __shared__ float sG[SKR_T][4];    // (g_x, g_y) per record of the round
+  __shared__ float sP[SKR_T][4];    // [v_posed; 1]
+  __shared__ int sRv[SKR_T];        // its vertex (-1: none)
+  __shared__ float sRed[SKR_T / 64][SKB_PART];
+  __shared__ float4 sAj[72];
+  __shared__ int sVid[SKR_CHUNK];
+  __shared__ short sSlot[SKR_CHUNK];
+  __shared__ int sCnt[SKR_VPT * (SKR_T / 64)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = blockIdx.y, v0 = blockIdx.x * SKR_CHUNK;
+  const float4 aj = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid < 72 ? tid : 71];
+  const float *cm = cam + (size_t)n * x_stride;
+  const float ck0 = cm[0], ck1 = cm[1];
+  int slot[SKR_VPT];
+#pragma unroll
+  for (int i = 0; i < SKR_VPT; ++i) {
+    const int v = v0 + i * SKR_T + tid;
+    const bool sampled = v < V && ((vs <= 1) || (v % vs == 0));
+    const int vpi = (vs <= 1) ? v : v / vs;
+    slot[i] = seg_vslot[(size_t)n * VP + min(vpi, VP - 1)];
+    if (!sampled) slot[i] = -1;
+  }
+  if (tid < 72) sAj[tid] = aj;
+  int pre[SKR_VPT];
+#pragma unroll
+  for (int i = 0; i < SKR_VPT; ++i) {
+    const unsigned long long m = __ballot(slot[i] >= 0);
+    pre[i] = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sCnt[i * (SKR_T / 64) + wave] = __popcll(m);
+  }
+  __syncthreads();
+  int R = 0;
+  {
+    int base[SKR_VPT] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < SKR_VPT * (SKR_T / 64); ++k) {
+      const int c = sCnt[k];
+#pragma unroll
+      for (int i = 0; i < SKR_VPT; ++i)
+        if (k < i * (SKR_T / 64) + wave) base[i] += c;
+      R += c;
+    }
+#pragma unroll
+    for (int i = 0; i < SKR_VPT; ++i) {
+      const int v = v0 + i * SKR_T + tid;
+      if (slot[i] >= 0) {
+        sVid[base[i] + pre[i]] = v;
+        sSlot[base[i] + pre[i]] = (short)slot[i];
+      } else if (v < V) {
+        float *o = dv_posed + ((size_t)n * V + v) * 3;
+        o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  const int li = lane & 15, lk = lane >> 4;
+  const int cr = li >> 2, cc = li & 3;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
+  for (int r0 = 0; r0 < R; r0 += SKR_T) {                  // (block-uniform; one round for up to 256 records)
+    const int idx = r0 + tid;
+    const bool valid = idx < R;
+    const int vid = sVid[min(idx, R - 1)], sl = sSlot[min(idx, R - 1)];
+    const float4 *tp = reinterpret_cast<const float4 *>(top4 + (size_t)vid * 8);
+    const float4 ww = tp[0], jj = tp[1];
+    const float *vp = v_posed + ((size_t)n * V + vid) * 3;
+    const float p0 = vp[0], p1 = vp[1], p2 = vp[2];
+    // the slot's sums over seg_bwd's row blocks, in block order (skin_bwd_kernel's gather, without the vertex -> slot hop)
+    const int win = sl / SB_SLOTS;
+    const float *sp = seg_part + ((size_t)n * seg_nsplit * SB_NWIN + win) * (SB_SLOTS * 2) + (sl - win * SB_SLOTS) * 2;
+    float sx = 0.0f, sy = 0.0f;
+    if (seg_nsplit <= 2) {
+      const float2 t0 = *reinterpret_cast<const float2 *>(sp);
+      const float2 t1 = *reinterpret_cast<const float2 *>(sp + (size_t)(seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
+      sx = t0.x + (seg_nsplit > 1 ? t1.x : 0.0f);
+      sy = t0.y + (seg_nsplit > 1 ? t1.y : 0.0f);
+    } else {
+      constexpr int GC = 6;
+      for (int s0 = 0; s0 < seg_nsplit; s0 += GC) {
+        float2 t[GC];
+#pragma unroll
+        for (int u = 0; u < GC; ++u)
+          t[u] = *reinterpret_cast<const float2 *>(sp + (size_t)min(s0 + u, seg_nsplit - 1) * (SB_NWIN * SB_SLOTS * 2));
+#pragma unroll
+        for (int u = 0; u < GC; ++u) {
+          sx += (s0 + u < seg_nsplit) ? t[u].x : 0.0f;
+          sy += (s0 + u < seg_nsplit) ? t[u].y : 0.0f;
+        }
+      }
+    }
+    const float gp0 = valid ? sx : 0.0f, gp1 = valid ? sy : 0.0f;
+    const float g0 = fmaf(ck0, gp0, 0.0f), g1 = fmaf(ck1, gp1, 0.0f);
+    const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
+    const int jx[4] = {(int)jj.x, (int)jj.y, (int)jj.z, (int)jj.w};
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                          // (row 2 of T only meets g_z = 0)
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {
+        const float4 rr = sAj[jx[jq] * 3 + r];
+        t0 = fmaf(w4[jq], rr.x, t0); t1 = fmaf(w4[jq], rr.y, t1); t2 = fmaf(w4[jq], rr.z, t2); t3 = fmaf(w4[jq], rr.w, t3);
+      }
+      const float gr = r == 0 ? g0 : g1;
+      dp0 = fmaf(t0, gr, dp0); dp1 = fmaf(t1, gr, dp1); dp2 = fmaf(t2, gr, dp2);
+      const float XY = fmaf(t2, p2, fmaf(t1, p1, fmaf(t0, p0, t3)));
+      if (r == 0) dku += XY * gp0; else dkv += XY * gp1;
+    }
+    du0 += gp0;
+    dv0 += gp1;
+    if (valid) {
+      float *o = dv_posed + ((size_t)n * V + vid) * 3;
+      o[0] = dp0; o[1] = dp1; o[2] = dp2;
+    }
+    sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = 0.f; sG[tid][3] = 0.f;
+    sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
+    sRv[tid] = valid ? vid : -1;
+    __syncthreads();
+    if (r0 + wave * 64 < R) {                              // (wave-uniform: this wave's 64 records hold at least one)
+      // the weights operand, gathered per record in MFMA layout: lane (li, lk) of step s holds
+      // w[vertex of record 64 wave + 4 s + lk][joint li] and [joint 16 + li]; a vertex of -1 reads zeros (range check)
+      float wa0[16], wa1[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int vt = sRv[wave * 64 + s * 4 + lk];
+        wa0[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (vt * 24 + li) * 4, 0, 0));
+        wa1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (vt * 24 + 16 + (li & 7)) * 4, 0, 0));
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int t = wave * 64 + s * 4 + lk;
+        const float a1 = (li < 8) ? wa1[s] : 0.0f;
+        const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[s], b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();                                       // (sG / sP / sRv are rewritten by the next round)
+  }
+  if (li < 12) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j0 = lk * 4 + r;
+      sRed[wave][j0 * 12 + li] = acc0[r];
+      if (j0 < 8) sRed[wave][(16 + j0) * 12 + li] = acc1[r];
+    }
+  }
+  const float q0 = wave_sum(dku), q1 = wave_sum(dkv), q2 = wave_sum(du0), q3 = wave_sum(dv0);
+  if (lane == 0) {
+    sRed[wave][288] = q0; sRed[wave][289] = q1; sRed[wave][290] = q2; sRed[wave][291] = q3;
+  }
+  __syncthreads();
+  for (int e = tid; e < SKB_PART; e += SKR_T) {
+    float acc = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < SKR_T / 64; ++wv) acc += sRed[wv][e];
+    part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
+  }
+}
+
 int skin_bwd_nblk(int V) { return (V + SKB_T - 1) / SKB_T; }
 
 int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg, const float *v_posed,
                              const float *lbs_weights, const float *lbs_top4, const float *A, const float *cam,
-                             int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st) {
+                             int x_stride, int B, int V, int vs, float *dv_posed, float *part, hipStream_t st,
+                             int *nblk_out) {
   const int VP = (V + vs - 1) / vs;
+  // SMPLR_SKIN_BWD_REC=0: the per-vertex kernel for every case (A/B runs)
+  static const bool rec_on = !(getenv("SMPLR_SKIN_BWD_REC") && atoi(getenv("SMPLR_SKIN_BWD_REC")) == 0);
+  if (rec_on && !dverts && !dproj && sg.part && lbs_top4) {
+    const dim3 grid((V + SKR_CHUNK - 1) / SKR_CHUNK, B);
+    hipLaunchKernelGGL(skin_bwd_rec_kernel, grid, dim3(SKR_T), 0, st, v_posed, lbs_weights, lbs_top4, A, cam, x_stride, B, V,
+                       vs, VP, dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot), sg.nsplit);
+    SMPLR_LAUNCH_CHECK("skin_bwd_rec_kernel");
+    *nblk_out = (int)grid.x;
+    return 0;
+  }
+  *nblk_out = skin_bwd_nblk(V);
   const dim3 grid(skin_bwd_nblk(V), (B + SKB_MB - 1) / SKB_MB);
   if (lbs_top4)
     hipLaunchKernelGGL(skin_bwd_kernel<true>, grid, dim3(SKB_T), 0, st, dverts, dproj, v_posed, lbs_weights, lbs_top4,
@@ -422,10 +616,10 @@ int smplr_skin_bwd(const float *dverts, const float *dproj, const float *v_posed
   SMPLR_REQUIRE(v_posed && lbs_weights && A && dv_posed && dA && workspace, "smplr_skin_bwd: null pointer");
   SMPLR_REQUIRE(dverts || dproj, "smplr_skin_bwd: need dverts and/or dproj");
   SMPLR_REQUIRE(!dproj || (cam && x_stride >= 4), "smplr_skin_bwd: dproj given without camera rows");
-  const int nblk = skin_bwd_nblk(V);
+  int nblk = 0;
   int rc = launch_skin_bwd_partials(dverts, dproj, SegGrad{nullptr, nullptr, 0}, v_posed, lbs_weights, lbs_top4, A, cam,
                                     x_stride, B, V, vertex_sampling, dv_posed, reinterpret_cast<float *>(workspace),
-                                    as_stream(stream));
+                                    as_stream(stream), &nblk);
   if (rc) return rc;
   hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(B), dim3(320), 0, as_stream(stream),
                      reinterpret_cast<const float *>(workspace), nblk, dA, dcam);

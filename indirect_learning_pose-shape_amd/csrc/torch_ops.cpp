@@ -17,6 +17,7 @@
 #include <torch/library.h>
 
 #include <initializer_list>
+#include <string>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -354,11 +355,18 @@ std::vector<Tensor> decoder_fwd_meta(const Tensor &x, const std::vector<Tensor> 
 }
 
 int64_t abi_version() { return smplr_abi_version(); }
+#ifndef SMPLR_TORCH_OPS_ID
+#define SMPLR_TORCH_OPS_ID "unknown"
+#endif
+// sha256 of this file (16 digits) + the torch version it was compiled against (csrc/Makefile): torch_ops.load() refuses a
+// layer built from another torch_ops.cpp or for another torch
+std::string build_tag() { return SMPLR_TORCH_OPS_ID; }
 
 }  // namespace
 
 TORCH_LIBRARY(smplraster, m) {
   m.def("abi_version() -> int", &abi_version);
+  m.def("build_tag() -> str", &build_tag);
   m.def("visibility(Tensor proj, int grid_wh=64, bool ref_compat=True) -> Tensor");
   m.def("project_fwd(Tensor verts, Tensor cam, int vertex_sampling=1) -> Tensor");
   m.def("project_bwd(Tensor dproj, Tensor verts, Tensor cam, int vertex_sampling=1) -> (Tensor, Tensor)");

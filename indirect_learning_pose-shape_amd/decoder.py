@@ -8,6 +8,8 @@ chain).  The op-by-op surface in `keras_smpl/` computes the same values.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -93,7 +95,10 @@ class SMPLDecoder(nn.Module):
         # two launches, outputs bit for bit; at batch 1 the eager forward is host-bound and this is what it costs
         if (labels is None and self.heads == ("seg",) and self.vs == 1 and self.streams == 1 and c.blend3_fwd is not None
                 and not (torch.is_grad_enabled() and x.requires_grad) and x.is_cuda and x.dtype == torch.float32
-                and x.shape[0] < ops.POSE_BLEND_SPLIT_B):
+                and x.shape[0] < ops.POSE_BLEND_SPLIT_B
+                # (the one-call op always skins inside the binning launch: an A/B run that switches that off must get
+                # the autograd node's launch sequence, which honours it)
+                and os.environ.get("SMPLR_FUSE_SKIN", "1") != "0"):
             from . import torch_ops
             if torch_ops.available():
                 o = torch_ops.load().decoder_fwd(x.contiguous(), c.as_list(), pt.part_pos, pt.part_off, self.img_wh,

@@ -25,6 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libsmplraster_torch.so")
 # op name -> schema, as csrc/torch_ops.cpp registers them (tests/test_abi.py compares with the loaded library)
 SCHEMAS = {
     "abi_version": "smplraster::abi_version() -> int",
+    "build_tag": "smplraster::build_tag() -> str",
     "visibility": "smplraster::visibility(Tensor proj, int grid_wh=64, bool ref_compat=True) -> Tensor",
     "project_fwd": "smplraster::project_fwd(Tensor verts, Tensor cam, int vertex_sampling=1) -> Tensor",
     "project_bwd": "smplraster::project_bwd(Tensor dproj, Tensor verts, Tensor cam, int vertex_sampling=1) -> (Tensor, Tensor)",
@@ -40,6 +41,17 @@ SCHEMAS = {
 }
 
 _ns = None
+
+
+def source_tag():
+    """sha256(csrc/torch_ops.cpp)[:16] + '-' + torch.__version__, as csrc/Makefile compiles it into build_tag(); None when
+    the source is not beside the library."""
+    import hashlib
+    src = os.path.join(_HERE, "csrc", "torch_ops.cpp")
+    if not os.path.exists(src):
+        return None
+    with open(src, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16] + "-" + torch.__version__
 
 
 def available() -> bool:
@@ -60,5 +72,9 @@ def load():
     ns = torch.ops.smplraster
     if int(ns.abi_version()) != _lib.ABI_VERSION:
         raise RuntimeError("libsmplraster_torch.so was linked against another ABI version of libsmplraster_hip.so")
+    want = source_tag()
+    if want is not None and ns.build_tag() != want:
+        raise RuntimeError("libsmplraster_torch.so was built from another torch_ops.cpp or for another torch (library %s, "
+                           "here %s): rebuild with `make -C indirect_learning_pose-shape_amd/csrc`" % (ns.build_tag(), want))
     _ns = ns
     return ns

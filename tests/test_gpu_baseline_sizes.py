@@ -288,7 +288,8 @@ def test_lds_attribute_table_follows_the_device_ordinal(smpl_model, blend_gemm, 
         torch.autograd.backward([out["seg"], out["silhouette"]], [g, gs])
         torch.cuda.synchronize()
         return out["seg"].detach().clone(), out["silhouette"].detach().clone(), xg.grad.clone()
-    prev = lib.smplr_debug_device_ordinal(7)            # an ordinal nothing has run under yet
+    o1, o2 = (7, 8) if blend_gemm == "bf16x3" else (9, 10)     # ordinals nothing has run under yet
+    prev = lib.smplr_debug_device_ordinal(o1)
     try:
         n0 = lib.smplr_debug_lds_attr_sets()
         a = step()
@@ -296,7 +297,7 @@ def test_lds_attribute_table_follows_the_device_ordinal(smpl_model, blend_gemm, 
         step()
         assert lib.smplr_debug_lds_attr_sets() == n1, "a second step on the same device set attributes again"
         assert n1 - n0 >= 3, "the step has at least three kernels above 48 KB of LDS (GEMM, binning, silhouette): %d" % (n1 - n0)
-        lib.smplr_debug_device_ordinal(8)
+        lib.smplr_debug_device_ordinal(o2)
         b = step()
         assert lib.smplr_debug_lds_attr_sets() - n1 == n1 - n0, "a new device ordinal must set every attribute again"
         assert all(torch.equal(p, q) for p, q in zip(a, b))

@@ -899,6 +899,49 @@ def test_seg_gradient_gathered_by_vertex_equals_merged(layer, smpl_model, vs, W,
     assert torch.allclose(d1, dproj, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("vs,W,all_visible,B", [(1, 48, False, 5), (2, 50, False, 3), (5, 48, False, 2), (1, 48, True, 2),
+                                                (1, 64, False, 130)])
+def test_skin_backward_over_records_equals_per_vertex(layer, smpl_model, vs, W, all_visible, B):
+    """Round 5: when the segmentation's slot sums are the only gradient, the skinning backward runs over the mesh's
+    RECORDS (skin_bwd_rec_kernel: vertices without a record have a zero row and are only zero-filled) instead of over
+    all 6 890 vertices.  Same terms, another summation order for dA and the camera sums: dx must agree with the
+    per-vertex kernel fed the merged dproj to fp32 rounding, be the same bits on every launch, and give the same bits for
+    a mesh whatever batch it sits in - also with vertex sampling, with > 4 096 records (slot windows, four rounds per
+    workgroup) and over a batch that fills the chip."""
+    from ilps_amd import ops
+    d = dev()
+    c = ops.SMPLConstants.from_model(smpl_model, d)
+    pt = ops.get_part_table(vs, d, c.V)
+    x = t(make_x(B, W, seed=700 + vs + B))
+    coef, Rs, J, A, Jt = ops._pose_fwd(x, 4, c)
+    vp = ops._blend_fwd(coef, c, B)
+    verts, proj = ops._skin_fwd(vp, A, c, cam=x, vertex_sampling=vs)
+    VP = proj.shape[1]
+    mask = torch.ones(B, VP, device=d) if all_visible else ops.visibility(proj)
+    vslot = torch.empty((B, VP), dtype=torch.int16, device=d)
+    seg, arg, rec = ops._seg_fwd(proj, mask, W, pt, vslot=vslot)
+    g = t(np.random.default_rng(19).normal(0, 1, (B, W, W, 32)))
+    part, nsplit = ops._seg_bwd(g, arg, rec, VP, W, pt, merge=False, deterministic=True)
+    dproj = ops._seg_bwd(g, arg, rec, VP, W, pt, deterministic=True)
+    want = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, None, dproj, None, vs)                     # per vertex (merged d proj)
+    got = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, None, None, None, vs, seg_grad=(part, vslot, nsplit))
+    again = ops._smpl_bwd(x, 4, c, Rs, J, A, vp, None, None, None, vs, seg_grad=(part, vslot, nsplit))
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+    grad_close(got.cpu().numpy(), want.cpu().numpy(), 2e-5, "dx (records) vs dx (vertices)")
+    # one mesh alone: the same bits (its partial sums do not depend on its neighbours)
+    k = B - 1
+    part1, ns1 = ops._seg_bwd(g[k:k + 1].contiguous(), arg[k:k + 1].contiguous(), rec[k:k + 1].contiguous(), VP, W, pt,
+                              merge=False, deterministic=True)
+    one = ops._smpl_bwd(x[k:k + 1].contiguous(), 4, c, Rs[k:k + 1].contiguous(), J[k:k + 1].contiguous(),
+                        A[k:k + 1].contiguous(), vp[k:k + 1].contiguous(), None, None, None, vs,
+                        seg_grad=(part1, vslot[k:k + 1].contiguous(), ns1))
+    if ns1 == nsplit:                     # (the row-block split follows the batch size; equal splits -> equal sums)
+        assert torch.equal(one[0], got[k])
+    else:
+        grad_close(one.cpu().numpy(), got[k:k + 1].cpu().numpy(), 2e-5, "dx alone vs in the batch")
+
+
 def test_pose_kernels_generic_tree_fallback(smpl_model):
     """The pose kernels run the kinematic chain by tree level when `parents` is the standard SMPL tree (a wave
     checks) and serially for any other tree: a model whose joints form one long chain (parent[i] = i - 1) and one
