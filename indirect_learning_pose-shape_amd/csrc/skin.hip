@@ -363,24 +363,37 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const float *__restric
 // the part rasteriser's (seg_bwd's slot sums; no d verts, no merged d proj: the decoder's training step), a vertex without
 // a record - hidden and further than 0.208 px from every pixel centre: 78 % of them - has g = 0: its dv_posed row is
 // zero and it adds nothing to dA or the camera sums, yet skin_bwd_kernel loads its weights and v_posed row, blends its T
-// and feeds it to the dA product like any other.  Here a workgroup takes 1 024 consecutive vertices, zero-fills the
-// dv_posed rows of those without a record as it reads their vslot, compacts the others ((vertex, slot) in vertex order:
-// ballot + prefix sums, no atomics, so the order - and with it every sum - is the same on every launch) and runs
-// skin_bwd_kernel's arithmetic on the compact list alone: the slot sums straight by slot (one hop instead of vertex ->
-// slot -> sums), T rows 0 and 1 (row 2 multiplies g_z = 0), the dA tile on the matrix cores with the weights gathered
-// per record.  dv_posed is bit for bit skin_bwd_kernel's; dA and the camera sums add the same terms in another order.
+// and feeds it to the dA product like any other.  Here a workgroup takes 1 024 consecutive vertices, compacts those with
+// a record ((vertex, slot) in vertex order: ballots + prefix sums, no atomics, so the order - and with it every sum - is
+// the same on every launch) and runs skin_bwd_kernel's arithmetic on the compact list alone: the slot sums straight by
+// slot (one hop instead of vertex -> slot -> sums), T rows 0 and 1 (row 2 multiplies g_z = 0), the dA tile on the matrix
+// cores with the weights operand rebuilt from the records' (weight, joint) quadruples in LDS.  dv_posed is bit for bit
+// skin_bwd_kernel's (rows without a record are stored as zeros); dA and the camera sums add the same terms in another
+// order.  Measured (rocprofv3, same box): B = 128 19.3-20.1 -> 16.1 us, B = 2 048 233-236 -> 138 us; the step 0.1253 ->
+// 0.1229 ms and 1.404 -> 1.297 ms (1.58 M meshes/s).  What the in-kernel stamps taught on the way
+// (tools/probes/skinrec_timeline.py): gfx950 counts loads and stores in ONE in-order counter, so the zero rows stored
+// during the compaction and the records' rows stored before the dA product made the next loads' waits 11.5 k and 4.7 k
+// clocks long - every store now comes behind the kernel's last load; gathering the dense weight rows per record (as
+// skin_bwd_kernel reads them) was a third dependent round trip of 5 k clocks.  A wave-private variant (no workgroup
+// barriers before the final sum) and 512- / 2 048-vertex workgroups were slower (tools: SMPLR_SKIN_BWD_REC=0 runs the
+// per-vertex kernel for A/B).
+#ifdef SMPLR_TL
+constexpr int TL_SKINREC_WG = 896;
+__device__ unsigned g_tl_skinrec[TL_SKINREC_WG * 4 * 32];
+#endif
 constexpr int SKR_T = 256;         // threads
 constexpr int SKR_VPT = 4;         // vertices per thread in the compaction pass
 constexpr int SKR_CHUNK = SKR_T * SKR_VPT;
 
-__global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
-    const float *__restrict__ v_posed, const float *__restrict__ lbs, const float *__restrict__ top4,
+__global__ __launch_bounds__(SKR_T) __attribute__((amdgpu_waves_per_eu(4, 8))) void skin_bwd_rec_kernel(
+    const float *__restrict__ v_posed, const float *__restrict__ top4,
     const float *__restrict__ A, const float *__restrict__ cam, int x_stride, int B, int V, int vs, int VP,
     float *__restrict__ dv_posed, float *__restrict__ part, const float *__restrict__ seg_part,
     const short *__restrict__ seg_vslot, int seg_nsplit) {
   __shared__ float sG[SKR_T][4];    // (g_x, g_y) per record of the round
   __shared__ float sP[SKR_T][4];    // [v_posed; 1]
-  __shared__ int sRv[SKR_T];        // its vertex (-1: none)
+  __shared__ float4 sW[SKR_T];      // its (up to) four skinning weights (zeros for a lane past the list) ...
+  __shared__ float4 sJ[SKR_T];      // ... and their joints
   __shared__ float sRed[SKR_T / 64][SKB_PART];
   __shared__ float4 sAj[72];
   __shared__ int sVid[SKR_CHUNK];
@@ -388,6 +401,7 @@ __global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
   __shared__ int sCnt[SKR_VPT * (SKR_T / 64)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = blockIdx.y, v0 = blockIdx.x * SKR_CHUNK;
+  SMPLR_TL_WAVE(g_tl_skinrec, SKR_T / 64, blockIdx.y * gridDim.x + blockIdx.x, TL_SKINREC_WG)
   const float4 aj = reinterpret_cast<const float4 *>(A + (size_t)n * 288)[tid < 72 ? tid : 71];
   const float *cm = cam + (size_t)n * x_stride;
   const float ck0 = cm[0], ck1 = cm[1];
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
     if (!sampled) slot[i] = -1;
   }
   if (tid < 72) sAj[tid] = aj;
+  SMPLR_TL_STAMP(1);
   int pre[SKR_VPT];
 #pragma unroll
   for (int i = 0; i < SKR_VPT; ++i) {
@@ -408,7 +423,9 @@ __global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
     pre[i] = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) sCnt[i * (SKR_T / 64) + wave] = __popcll(m);
   }
+  SMPLR_TL_STAMP(2);
   __syncthreads();
+  SMPLR_TL_STAMP(3);
   int R = 0;
   {
     int base[SKR_VPT] = {0, 0, 0, 0};
@@ -426,17 +443,15 @@ __global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
       if (slot[i] >= 0) {
         sVid[base[i] + pre[i]] = v;
         sSlot[base[i] + pre[i]] = (short)slot[i];
-      } else if (v < V) {
-        float *o = dv_posed + ((size_t)n * V + v) * 3;
-        o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
       }
     }
   }
+  SMPLR_TL_STAMP(4);
   __syncthreads();
+  SMPLR_TL_STAMP(5);
   const int li = lane & 15, lk = lane >> 4;
   const int cr = li >> 2, cc = li & 3;
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lbs), 0, V * 24 * 4, 0x00020000);
+  const float fl0 = (float)li, fl1 = (float)(16 + li);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   float dku = 0.f, dkv = 0.f, du0 = 0.f, dv0 = 0.f;
   for (int r0 = 0; r0 < R; r0 += SKR_T) {                  // (block-uniform; one round for up to 256 records)
@@ -490,35 +505,51 @@ __global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
     }
     du0 += gp0;
     dv0 += gp1;
+    sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = 0.f; sG[tid][3] = 0.f;
+    sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
+    sW[tid] = valid ? ww : make_float4(0.f, 0.f, 0.f, 0.f);
+    sJ[tid] = jj;
+    SMPLR_TL_STAMP(6);
+    __syncthreads();
+    SMPLR_TL_STAMP(7);
+    if (r0 + wave * 64 < R) {                              // (wave-uniform: this wave's 64 records hold at least one)
+      // dA tile: D[joint][comp] += sum_k w[record k][joint] * g[k][comp >> 2] * [v_posed; 1][k][comp & 3].  Lane (li, lk)
+      // of step s holds record 64 wave + 4 s + lk: its weight for joint li (and 16 + li) - rebuilt from the record's
+      // (weight, joint) quadruple in LDS: the quadruple's weight for that joint, else 0, the very numbers
+      // skin_bwd_kernel gathers from the dense (V, 24) table (a third dependent round trip here: 5 k clocks)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int t = wave * 64 + s * 4 + lk;
+        const float4 wq = sW[t], jq = sJ[t];
+        const float a0 = ((jq.x == fl0 ? wq.x : 0.0f) + (jq.y == fl0 ? wq.y : 0.0f)) +
+                         ((jq.z == fl0 ? wq.z : 0.0f) + (jq.w == fl0 ? wq.w : 0.0f));
+        const float a1 = ((jq.x == fl1 ? wq.x : 0.0f) + (jq.y == fl1 ? wq.y : 0.0f)) +
+                         ((jq.z == fl1 ? wq.z : 0.0f) + (jq.w == fl1 ? wq.w : 0.0f));
+        const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(li < 8 ? a1 : 0.0f, b, acc1, 0, 0, 0);
+      }
+    }
+    // (every store of the kernel comes behind its loads: gfx950 counts loads and stores in ONE in-order counter, so a
+    // wait for a load is a wait for every store the wave issued before it - with the zero rows stored during the
+    // compaction and the records' rows before the dA product, the waves sat 11.5 k and 4.7 k clocks in those two waits)
     if (valid) {
       float *o = dv_posed + ((size_t)n * V + vid) * 3;
       o[0] = dp0; o[1] = dp1; o[2] = dp2;
     }
-    sG[tid][0] = g0; sG[tid][1] = g1; sG[tid][2] = 0.f; sG[tid][3] = 0.f;
-    sP[tid][0] = p0; sP[tid][1] = p1; sP[tid][2] = p2; sP[tid][3] = 1.0f;
-    sRv[tid] = valid ? vid : -1;
-    __syncthreads();
-    if (r0 + wave * 64 < R) {                              // (wave-uniform: this wave's 64 records hold at least one)
-      // the weights operand, gathered per record in MFMA layout: lane (li, lk) of step s holds
-      // w[vertex of record 64 wave + 4 s + lk][joint li] and [joint 16 + li]; a vertex of -1 reads zeros (range check)
-      float wa0[16], wa1[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int vt = sRv[wave * 64 + s * 4 + lk];
-        wa0[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (vt * 24 + li) * 4, 0, 0));
-        wa1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (vt * 24 + 16 + (li & 7)) * 4, 0, 0));
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int t = wave * 64 + s * 4 + lk;
-        const float a1 = (li < 8) ? wa1[s] : 0.0f;
-        const float b = (li < 12) ? sG[t][cr] * sP[t][cc] : 0.0f;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[s], b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
-      }
-    }
+    SMPLR_TL_STAMP(8);
     __syncthreads();                                       // (sG / sP / sRv are rewritten by the next round)
   }
+  // the rows of the vertices without a record
+#pragma unroll
+  for (int i = 0; i < SKR_VPT; ++i) {
+    const int v = v0 + i * SKR_T + tid;
+    if (slot[i] < 0 && v < V) {
+      float *o = dv_posed + ((size_t)n * V + v) * 3;
+      o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f;
+    }
+  }
+  SMPLR_TL_STAMP(9);
   if (li < 12) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -532,12 +563,17 @@ __global__ __launch_bounds__(SKR_T) void skin_bwd_rec_kernel(
     sRed[wave][288] = q0; sRed[wave][289] = q1; sRed[wave][290] = q2; sRed[wave][291] = q3;
   }
   __syncthreads();
+  SMPLR_TL_STAMP(10);
   for (int e = tid; e < SKB_PART; e += SKR_T) {
     float acc = 0.f;
 #pragma unroll
     for (int wv = 0; wv < SKR_T / 64; ++wv) acc += sRed[wv][e];
     part[((size_t)n * gridDim.x + blockIdx.x) * SKB_PART + e] = acc;
   }
+  SMPLR_TL_STAMP(11);
+#ifdef SMPLR_TL
+  if (tl__) tl__[12] = (unsigned)R;
+#endif
 }
 
 int skin_bwd_nblk(int V) { return (V + SKB_T - 1) / SKB_T; }
@@ -551,8 +587,8 @@ int launch_skin_bwd_partials(const float *dverts, const float *dproj, SegGrad sg
   static const bool rec_on = !(getenv("SMPLR_SKIN_BWD_REC") && atoi(getenv("SMPLR_SKIN_BWD_REC")) == 0);
   if (rec_on && !dverts && !dproj && sg.part && lbs_top4) {
     const dim3 grid((V + SKR_CHUNK - 1) / SKR_CHUNK, B);
-    hipLaunchKernelGGL(skin_bwd_rec_kernel, grid, dim3(SKR_T), 0, st, v_posed, lbs_weights, lbs_top4, A, cam, x_stride, B, V,
-                       vs, VP, dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot), sg.nsplit);
+    hipLaunchKernelGGL(skin_bwd_rec_kernel, grid, dim3(SKR_T), 0, st, v_posed, lbs_top4, A, cam, x_stride, B, V, vs, VP,
+                       dv_posed, part, sg.part, reinterpret_cast<const short *>(sg.vslot), sg.nsplit);
     SMPLR_LAUNCH_CHECK("skin_bwd_rec_kernel");
     *nblk_out = (int)grid.x;
     return 0;
@@ -659,4 +695,5 @@ int smplr_project_bwd(const float *dproj, const float *verts, const float *cam, 
 
 #ifdef SMPLR_TL
 SMPLR_TL_EXPORT(skin, smplr::g_tl_skin, smplr::TL_SKIN_WG * (smplr::SKB_T / 64) * 32)
+SMPLR_TL_EXPORT(skinrec, smplr::g_tl_skinrec, smplr::TL_SKINREC_WG * 4 * 32)
 #endif
