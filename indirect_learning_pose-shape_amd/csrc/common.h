@@ -149,7 +149,13 @@ __device__ __forceinline__ void skin_T_sparse(const float4 *sAj, const float4 ww
   for (int e = 0; e < 12; ++e) T[e] = 0.0f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+#if defined(SMPLR_KO_SKIN_NOLDS)      // knock-outs (tools/build_variant.sh; wrong results on purpose): no LDS read at all ...
+    const float4 r0 = make_float4(jj.x, jj.y, jj.z, jj.w), r1 = make_float4(jj.y, jj.x, jj.w, jj.z), r2 = make_float4(jj.w, jj.z, jj.y, jj.x);
+#elif defined(SMPLR_KO_SKIN_JOINT0)   // ... / every lane reads joint k's rows (pure broadcast: no bank conflict)
+    const float4 r0 = sAj[k * 3], r1 = sAj[k * 3 + 1], r2 = sAj[k * 3 + 2];
+#else
     const float4 r0 = sAj[jx[k] * 3], r1 = sAj[jx[k] * 3 + 1], r2 = sAj[jx[k] * 3 + 2];
+#endif
     const float wj = w[k];
     T[0] = fmaf(wj, r0.x, T[0]); T[1] = fmaf(wj, r0.y, T[1]); T[2] = fmaf(wj, r0.z, T[2]); T[3] = fmaf(wj, r0.w, T[3]);
     T[4] = fmaf(wj, r1.x, T[4]); T[5] = fmaf(wj, r1.y, T[5]); T[6] = fmaf(wj, r1.z, T[6]); T[7] = fmaf(wj, r1.w, T[7]);

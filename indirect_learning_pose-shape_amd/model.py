@@ -29,7 +29,8 @@ class PReLU(nn.PReLU):
         super().__init__(num_parameters, init=init, **kw)
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and self.weight.numel() == x.shape[1]:
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2 and self.weight.numel() == x.shape[1]
+                and x.is_contiguous()):           # (NCHW planes; a channels_last tensor takes the stock op)
             from . import ops
             return ops.PReLUFn.apply(x.contiguous(), self.weight)
         return super().forward(x)

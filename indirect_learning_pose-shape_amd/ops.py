@@ -822,7 +822,9 @@ class BatchNormResActFn(torch.autograd.Function):
 
 
 def _bn_fusable(x, bn):
-    return (bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine
+    # (x.is_contiguous(): the kernels read NCHW planes - a channels_last tensor, the opt-in SMPLR_ENCODER_LAYOUT of
+    # training.py, takes the stock modules instead of being transposed back for them)
+    return (bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine and x.is_contiguous()
             and bn.track_running_stats and bn.momentum is not None and x.shape[2] * x.shape[3] >= 256
             and x.shape[0] > 0)
 
@@ -850,7 +852,7 @@ def batch_norm_act(x, bn, act=None):
     """`act(bn(x))` for a torch.nn.BatchNorm2d and an optional per-channel nn.PReLU.  Training mode on a HIP
     device with planes of >= 256 elements runs the fused HIP kernels; everything else (eval mode, CPU, tiny
     planes, other dtypes) takes the stock modules.  Parameters, buffers and state dict are the modules' own."""
-    fused = (bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine
+    fused = (bn.training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine and x.is_contiguous()
              and bn.track_running_stats and bn.momentum is not None and x.shape[2] * x.shape[3] >= 256
              and (act is None or act.weight.numel() == x.shape[1]) and x.shape[0] > 0)
     if not fused:

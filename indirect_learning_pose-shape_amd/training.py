@@ -46,6 +46,14 @@ class SegTrainer:
             configure_conv_backend()
         self.output_wh = output_wh
         self.smpl_model = SMPLRegressor(output_wh, encoder_architecture, use_IEF).to(self.device)
+        # OPT-IN (`SMPLR_ENCODER_LAYOUT=channels_last`): the encoder's weights and activations in NHWC, the layout
+        # MIOpen's implicit-GEMM convolution solvers work in (the default NCHW tensors are transposed around them:
+        # `batched_transpose_32x32_dword` in the train step's kernel trace).  The package's fused batch-norm / PReLU
+        # kernels read NCHW planes, so this layout runs the stock modules for them.  Measured before being made a default:
+        # tools/train_layout_ab.py.
+        self.channels_last = os.environ.get("SMPLR_ENCODER_LAYOUT", "").lower() == "channels_last"
+        if self.channels_last:
+            self.smpl_model = self.smpl_model.to(memory_format=torch.channels_last)
         self.loss_fn = softmax_focal_loss(gamma, weight_classes)      # softmax + focal loss, one HIP kernel
         self.silh_loss_fn = softmax_focal_loss(0.0, False)            # softmax + categorical CE
         # the train pass consumes losses only: verts / projects / mask are not written out, and with an integer class
@@ -76,6 +84,8 @@ class SegTrainer:
         mark = (lambda k: None) if _marks is None else _marks
         mark("start")
         self.opt.zero_grad(set_to_none=True)
+        if self.channels_last and images.dim() == 4 and images.shape[1] == 3:
+            images = images.contiguous(memory_format=torch.channels_last)
         param = self.net(images)
         mark("encoder_fwd")
         if _marks is not None and param.requires_grad:
