@@ -1749,7 +1749,7 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
   const float *grow = dseg + row0 * 32 + ch;
   int a[NB][U];
   float g[NB][U];
-  float4 rv[NB][U];
+  f32x3g rv[NB][U];                            // (u, v, m^2): 12 of a record's 16 bytes - the vertex id is not used here
   int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
   float sx = 0.0f, sy = 0.0f;
 #ifdef SMPLR_TL
@@ -1773,14 +1773,14 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
   asm volatile("" : : : "memory");                                                                              \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                               \
     g[b_][u] = g[b_][u] - __shfl((a[b_][u] == 1) ? g[b_][u] : 0.0f, 0, 32);                                     \
-    rv[b_][u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rrs, a[b_][u] * 16, 0, 0));    \
+    rv[b_][u] = __builtin_bit_cast(f32x3g, __builtin_amdgcn_raw_buffer_load_b96(rrs, a[b_][u] * 16, 0, 0));     \
   }
   static_assert(NB > 1 && 2 * U <= SB_PF, "the first TWO batches come from the SB_PF pixels requested at kernel entry");
   // the channel-0 broadcast alone, for the batch whose records were gathered at kernel entry (prv)
 #define SMPLR_SB_PRE(b_)                                                                                        \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                               \
     g[b_][u] = g[b_][u] - __shfl((a[b_][u] == 1) ? g[b_][u] : 0.0f, 0, 32);                                     \
-    rv[b_][u] = make_float4(prv[u].x, prv[u].y, prv[u].z, 0.0f);                                                \
+    rv[b_][u] = prv[u];                                                                                         \
   }
   static_assert(U <= SB_PRE, "the first batch's records come from the kernel's entry");
 #pragma unroll
@@ -2133,6 +2133,7 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
 #pragma unroll
         for (int u = 0; u < SB_PRE; ++u) asm volatile("" : "+v"(prv[u].x), "+v"(prv[u].y), "+v"(prv[u].z));
       }
+
       if (LOSS) {
         asm volatile("" : "+v"(warm));
         if (nwin == 1 && fast && W == 48 && pipe)
