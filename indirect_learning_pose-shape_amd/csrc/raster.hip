@@ -1602,8 +1602,6 @@ __global__ __launch_bounds__(PL * NG2, (PL * NG2 > 512 ? 8 : 4)) SMPLR_RASTER_SG
 // (SB_SLOTS = 4096 accumulators per window, SB_NWIN = 5 windows, 8 or 24 rows per block by batch size: common.h)
 constexpr int SB_U = 8;          // pixels in flight per lane
 constexpr int SB_PF = 12;        // pixels of a row requested at kernel entry (>= SB_U)
-constexpr int SB_PRE = 6;        // ... and pixels whose arg-min records are gathered there too (the pipelined walk's first batch)
-typedef float f32x3g __attribute__((ext_vector_type(3)));
 
 // (unconditional: a run that ends has a non-zero sum except by cancellation, and the walk starts on slot 0 with a sum
 // of zero, so the tests that used to guard this - slot valid, sum non-zero - only cost their instructions, in a kernel
@@ -1736,11 +1734,11 @@ __device__ __forceinline__ void seg_bwd_row(const float *__restrict__ dseg, cons
 // summed: a wave's walk is as long as its vector work alone.  Fully unrolled (W = 48: 8 batches of 6 pixels, W = 64: 16 of 4 - the registers of three batches in flight
 // beside the walk's own 59 must stay within the 168 a 768-thread block allows), so the three
 // batches in flight are register names, not copies.  Same arithmetic, same order of flushes as seg_bwd_row.
+typedef float f32x3g __attribute__((ext_vector_type(3)));
 template <int U, int NB, bool DET>
 __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg, const short *__restrict__ arg,
                                                  const float4 *__restrict__ R, int rbytes, float *acc, size_t row0,
-                                                 int ch, float fr, float scale, const int *pa, const float *pg,
-                                                 const f32x3g *prv) {
+                                                 int ch, float fr, float scale, const int *pa, const float *pg) {
   unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(acc);
   const bool chok = ch >= 1;
   const __amdgpu_buffer_rsrc_t rrs =
@@ -1749,7 +1747,8 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
   const float *grow = dseg + row0 * 32 + ch;
   int a[NB][U];
   float g[NB][U];
-  f32x3g rv[NB][U];                            // (u, v, m^2): 12 of a record's 16 bytes - the vertex id is not used here
+  // (u, v, m^2): 12 of a record's 16 bytes - the vertex id is not used here (round 5: B = 2 048 285 -> 282 us)
+  f32x3g rv[NB][U];
   int cur = 0;                                   // (slot 0 with a sum of zero: the first flush adds nothing)
   float sx = 0.0f, sy = 0.0f;
 #ifdef SMPLR_TL
@@ -1776,21 +1775,14 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
     rv[b_][u] = __builtin_bit_cast(f32x3g, __builtin_amdgcn_raw_buffer_load_b96(rrs, a[b_][u] * 16, 0, 0));     \
   }
   static_assert(NB > 1 && 2 * U <= SB_PF, "the first TWO batches come from the SB_PF pixels requested at kernel entry");
-  // the channel-0 broadcast alone, for the batch whose records were gathered at kernel entry (prv)
-#define SMPLR_SB_PRE(b_)                                                                                        \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                               \
-    g[b_][u] = g[b_][u] - __shfl((a[b_][u] == 1) ? g[b_][u] : 0.0f, 0, 32);                                     \
-    rv[b_][u] = prv[u];                                                                                         \
-  }
-  static_assert(U <= SB_PRE, "the first batch's records come from the kernel's entry");
 #pragma unroll
-  for (int u = 0; u < U; ++u) {                  // batches 0 and 1 were requested at kernel entry - rows AND (round 5)
-    a[0][u] = pa[u];                             // records: the walk starts on data that arrived under the zeroing of
-    g[0][u] = pg[u];                             // the accumulators and its barrier
+  for (int u = 0; u < U; ++u) {                  // batches 0 and 1 were requested at kernel entry: the walk starts with
+    a[0][u] = pa[u];                             // both gathers instead of a round trip for batch 1's rows
+    g[0][u] = pg[u];
     a[1][u] = pa[U + u];
     g[1][u] = pg[U + u];
   }
-  SMPLR_SB_PRE(0)
+  SMPLR_SB_GATHER(0)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     // (scheduling fences: unrolled, the compiler would otherwise hoist EVERY batch's loads to the top - 185 spills)
@@ -1828,7 +1820,6 @@ __device__ __forceinline__ void seg_bwd_row_pipe(const float *__restrict__ dseg,
   }
 #undef SMPLR_SB_LOAD
 #undef SMPLR_SB_GATHER
-#undef SMPLR_SB_PRE
   if (DET) seg_flush_det(acc64, cur, sx, sy, scale);
   else seg_flush(acc, cur, sx, sy);
 }
@@ -2064,22 +2055,6 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
     }
     if (LOSS) warm = reinterpret_cast<const float *>(li.stats + row0)[ch];
   }
-  // Round 5: the arg-min RECORDS of those first two batches are gathered here as well, as soon as the slots are in: the
-  // walk used to issue its first gather behind the zeroing's barrier and sat out the round trip (round 4's stamps: zeroed
-  // at 3.8 k clocks, first batch gathered at 8.0 k).  Speculative: only the pipelined walk (one slot window, C = 32,
-  // W = 48 / 64) uses them; a slot of -1 reads zeros as in the walk (the descriptor's range check).
-  // (the first batch only - 6 pixels at W = 48, 4 at W = 64 - and 12 of a record's 16 bytes, the vertex id is not used
-  // here: with both batches' whole records the kernel spilled 39 registers)
-  f32x3g prv[SB_PRE];
-#pragma unroll
-  for (int u = 0; u < SB_PRE; ++u) prv[u] = f32x3g{0.f, 0.f, 0.f};
-  if (!LOSS && fast && pipe && ro < W && (W == 48 || W == 64)) {   // block-uniform but for `ro`
-    const __amdgpu_buffer_rsrc_t rrs0 =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(R), 0, S * 16, 0x00020000);
-#pragma unroll
-    for (int u = 0; u < SB_PRE; ++u)
-      prv[u] = __builtin_bit_cast(f32x3g, __builtin_amdgcn_raw_buffer_load_b96(rrs0, pa[u] * 16, 0, 0));
-  }
   if (dproj) {                                                // (NULL: the consumer gathers the slot sums itself)
     // this block's share of the mesh's dproj rows := 0 (the merge kernel then stores the sums)
     float *dp = dproj + (size_t)n * VP * 3;
@@ -2129,11 +2104,6 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
       // (the compiler would otherwise start on the first batch - and wait for it - in front of the barrier)
 #pragma unroll
       for (int u = 0; u < SB_PF; ++u) asm volatile("" : "+v"(pa[u]), "+v"(pg[u]));
-      if (!LOSS) {
-#pragma unroll
-        for (int u = 0; u < SB_PRE; ++u) asm volatile("" : "+v"(prv[u].x), "+v"(prv[u].y), "+v"(prv[u].z));
-      }
-
       if (LOSS) {
         asm volatile("" : "+v"(warm));
         if (nwin == 1 && fast && W == 48 && pipe)
@@ -2147,9 +2117,9 @@ __global__ __launch_bounds__(32 * SB_ROWS_BIG) void seg_bwd_kernel(const float *
         else
           seg_bwd_row_loss<true, false, DET>(li, arg, R, S * 16, acc, row0, W, C, ch, fr, base, scale, pa, pg);
       } else if (nwin == 1 && fast && W == 48 && pipe)
-        seg_bwd_row_pipe<6, 8, DET>(dseg, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg, prv);
+        seg_bwd_row_pipe<6, 8, DET>(dseg, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg);
       else if (nwin == 1 && fast && W == 64 && pipe)
-        seg_bwd_row_pipe<4, 16, DET>(dseg, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg, prv);
+        seg_bwd_row_pipe<4, 16, DET>(dseg, arg, R, S * 16, acc, row0, ch, fr, scale, pa, pg);
       else if (nwin == 1 && fast)
         seg_bwd_row<false, true, DET>(dseg, arg, R, S * 16, acc, row0, W, C, ch, fr, 0, scale, pa, pg);
       else if (nwin == 1)

@@ -41,12 +41,7 @@ def test_raster_fwd_keeps_two_blocks_per_cu(kernels):
 def test_hot_path_kernels_fit_their_launch(kernels, pat, threads, blocks):
     """`blocks` workgroups of `threads` threads fit a CU's registers (4 SIMDs), without scratch."""
     for name, k in _match(kernels, pat).items():
-        # (seg_bwd_kernel, round 5: the records of the walk's first batch are gathered at kernel entry and held - 18
-        # registers - across the accumulators' zeroing; at the 168 registers a 768-thread block allows the compiler parks
-        # four address pairs in scratch there, stored once in the prologue and reloaded once at the walk's set-up (8
-        # scratch instructions outside every loop, checked in the ISA); measured with them: 20.3-21.4 -> 19.6 us at B = 128)
-        cold = 64 if pat == "seg_bwd_kernel" else 0
-        assert k["scratch"] <= cold, "%s spills %d B per lane" % (name, k["scratch"])
+        assert k["scratch"] == 0, "%s spills %d B per lane" % (name, k["scratch"])
         assert k["max_threads"] >= threads, name
         need = -(-blocks * (threads // 64) // 4)
         assert kr.waves_per_simd(k) >= need, "%s: %d waves per SIMD, the launch needs %d" % (name, kr.waves_per_simd(k), need)
