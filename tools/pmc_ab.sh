@@ -4,13 +4,14 @@
 #   LIBS="old new" BENCH_ARGS="--step fused_loss" bash tools/pmc_ab.sh FILT "SET 1" ["SET 2" ...]
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 PKG=indirect_learning_pose-shape_amd; FILT=$1; shift
-cp $PKG/libsmplraster_hip.so $PKG/lib_keep.so
-for v in ${LIBS:-old new}; do
-  cp $PKG/lib_$v.so $PKG/libsmplraster_hip.so
+# (libraries through SMPLR_LIB_PATH - "keep" = the product library, which is never overwritten)
+for v in ${LIBS:-keep}; do
+  L=$GRAFT_REPO_ROOT/$PKG/lib_$v.so; [ "$v" = keep ] && L=
+  export SMPLR_LIB_PATH=$L
   i=0
   for SET in "$@"; do
     i=$((i+1)); D=gpurun_out/pmcab_${v}_$i; rm -rf $D
-    timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $D -- python3 bench.py --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg --min-warmup 0 $BENCH_ARGS > $D.log 2>&1 || { tail -20 $D.log; cp $PKG/lib_keep.so $PKG/libsmplraster_hip.so; exit 1; }
+    timeout -k 10 300 rocprofv3 --pmc $SET --output-format csv -d $D -- python3 bench.py --steps 3 --warmup 2 --mode eager --no-cpu-baseline --no-breakdown --no-train-leg --min-warmup 0 $BENCH_ARGS > $D.log 2>&1 || { tail -20 $D.log; exit 1; }
     python3 - "$v" "$D" "$FILT" <<'PY'
 import collections, csv, glob, re, sys
 acc = collections.defaultdict(list)
@@ -23,4 +24,3 @@ for k, v in sorted(acc.items()):
 PY
   done
 done
-cp $PKG/lib_keep.so $PKG/libsmplraster_hip.so
