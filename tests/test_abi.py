@@ -161,3 +161,47 @@ def test_torch_library_registers_the_declared_ops():
                        m(2, 6890, 3)).shape == (2, 86)
     with pytest.raises((RuntimeError, NotImplementedError)):
         ns.visibility(torch.zeros(1, 10, 3))                 # a CPU tensor: no kernel registered for it
+
+
+def test_seg_raster_plan_is_host_arithmetic():
+    """smplr_seg_raster_plan (ABI 7) launches nothing: the block shape by batch and the records one pass over a tile's LDS
+    table takes, as raster2_fwd_kernel computes them - 128 pair-lanes x 8 part ranges with tables of 800 (tiles over 8
+    image rows) / 1 032 records at W = 48 and 1 444 at W = 64, 64 x 10 with 1 228 for the small batches at W <= 48 with the
+    full part table; a tile over more than 10 image rows (W = 12 in 64-lane blocks) cannot take the table form at all."""
+    import ctypes
+    from ilps_amd import _lib
+    lib = _lib.load()
+
+    def plan(B, W, K=6879, P=31):
+        info = (ctypes.c_int32 * 8)()
+        nt = lib.smplr_seg_raster_plan(B, W, P, K, info, None)
+        tiles = (ctypes.c_int32 * max(nt, 1))()
+        assert lib.smplr_seg_raster_plan(B, W, P, K, info, tiles) == nt
+        return nt, list(info), list(tiles)[:nt]
+    nt, info, tiles = plan(128, 48)
+    assert nt == 9 and info[:4] == [128, 8, 9, 31 + 2 + 32] and tiles == [1032, 800, 1032] * 3
+    assert info[4:7] == [1032, 800, 0]
+    nt, info, tiles = plan(128, 64)
+    assert nt == 16 and set(tiles) == {1444} and info[0] == 128
+    nt, info, tiles = plan(8, 48)
+    assert nt == 18 and info[:2] == [64, 10] and set(tiles) == {1228}
+    nt, info, tiles = plan(128, 48, K=1376)                    # every fifth vertex: the large shape at every batch
+    assert info[0] == 128 and nt == 9
+    nt, info, tiles = plan(4, 12)
+    assert 0 in tiles and info[6] == 1                         # some tile spans more than 10 image rows
+    assert lib.smplr_seg_raster_plan(0, 48, 31, 6879, None, None) == 0
+    assert lib.smplr_seg_raster_plan(4, 161, 31, 6879, None, None) == 0
+    assert lib.smplr_seg_raster_plan(4, 48, 32, 6879, None, None) == 0
+
+
+def test_debug_device_ordinal_round_trips():
+    from ilps_amd import _lib
+    lib = _lib.load()
+    prev = lib.smplr_debug_device_ordinal(5)
+    try:
+        assert lib.smplr_debug_device_ordinal(70) == 5          # (clamped to the table: 63)
+        assert lib.smplr_debug_device_ordinal(-1) == 63
+        assert lib.smplr_debug_device_ordinal(-1) == -1
+        assert lib.smplr_debug_lds_attr_sets() >= 0
+    finally:
+        lib.smplr_debug_device_ordinal(prev)
