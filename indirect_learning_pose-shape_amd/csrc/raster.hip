@@ -1040,8 +1040,10 @@ __global__ __launch_bounds__(RTS * NG) SMPLR_RASTER_SGPRS void raster_fwd_kernel
 //  * two block shapes, PL pair-lanes x NG2 part ranges: 128 x 8 (two blocks per CU) and 64 x 10 (three) for batches
 //    that would not fill two rounds of the large one (raster2_shape).
 // Keys, tie rules, merge and write-out are raster_fwd_kernel's, expression for expression: outputs are bit-identical
-// (tools/probes/seg_hash.py).  Blocks whose tables do not fit (list longer than TREC(R), a weight other than 1, more
-// than 10 image rows under the block) walk the global record list with scalar loads - exact, slow, rare.
+// (tools/probes/seg_hash.py).  A list longer than the table (TREC(R) records) goes through it in chunks (round 5:
+// scan2_parts_chunk below - rounds 1-4 walked such lists with scalar loads, 1.7 x slower at 3 000 records); blocks with a
+// weight other than 1 in the list, or more than 10 image rows under them, still walk the global record list with scalar
+// loads - exact, slow, and not what the reference's masks ({1, 500}) or sizes (48, 64) produce.
 constexpr int PLN = 128;                 // pair-lanes per block: 2 x 64 (the large-batch shape)
 // The block shape by batch: 1 = 128 pair-lanes x 8 part ranges (two blocks per CU), 2 = 64 x 10 (three per CU).  The
 // small blocks cost a second table build per 256 pixels and pay while the large ones would leave CUs idle or

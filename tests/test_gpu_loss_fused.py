@@ -180,15 +180,19 @@ def test_fused_loss_argument_errors(layer):
     assert lib.smplr_seg_loss_bwd(None, None, None, None, 0, 6890, 48, 31, 6879, None, None, 0, None) == 0
 
 
-@pytest.mark.parametrize("B,W,with_silh,vs", [(3, 48, False, None), (128, 48, False, None), (5, 48, True, None),
-                                              (2, 64, False, None), (2, 128, False, None), (3, 48, False, 5)])
-def test_decoder_with_fused_loss_equals_unfused(smpl_model, B, W, with_silh, vs):
+@pytest.mark.parametrize("B,W,with_silh,vs,scale", [(3, 48, False, None, 1.0), (128, 48, False, None, 1.0), (5, 48, True, None, 1.0),
+                                                    (2, 64, False, None, 1.0), (2, 128, False, None, 1.0), (3, 48, False, 5, 1.0),
+                                                    # a body 2.5 x larger in the image: record lists of 1 500+ (two to three
+                                                    # chunks through the rasteriser's table, round 5), both block shapes
+                                                    (4, 48, False, None, 2.5), (120, 48, False, None, 2.5)])
+def test_decoder_with_fused_loss_equals_unfused(smpl_model, B, W, with_silh, vs, scale):
     """SMPLDecoder(loss=softmax_focal_loss(...)): forward(x, labels) returns the per-pixel loss without ever writing
     the scores; loss and dx agree with the unfused decoder + loss head.  W = 128 and vertex_sampling = 5 take the
     two-call path (the skinning form of the binning kernel does not apply there), B = 128 is BASELINE configs[2]'s batch."""
     from ilps_amd.decoder import SMPLDecoder
     from ilps_amd.focal_loss import softmax_focal_loss
     x = make_x(B, W, seed=B + W)
+    x[:, 0:2] *= scale
     lf = softmax_focal_loss(2.0, True)
     plain = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, vertex_sampling=vs)
     fused = SMPLDecoder(smpl_model, img_wh=W, with_silhouette=with_silh, vertex_sampling=vs, loss=lf, outputs=(),
