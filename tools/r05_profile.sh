@@ -15,7 +15,11 @@ if [ "$MODE" = main ]; then
   cp $(ls $O/prof_eager/*/*_kernel_stats.csv | head -1) $O/eager_kernel_stats.csv 2>/dev/null
   # the same box's headline right after the trace: three short runs of the graph-replayed step
   for i in 1 2 3; do timeout -k 10 200 python bench.py --steps 50 --no-cpu-baseline --no-breakdown --no-train-leg 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); w=l['ms_per_step_windows']; print(l['ms_per_step'], w['min'], w['median'], w['max'], l['ms_per_step_graph1'], l['build_id'][:12])"; done > $O/headline_runs.txt
-  python tools/same_box.py $O/eager_kernel_stats.csv $O/headline_runs.txt $O/bench.json > $O/same_box.txt; cat $O/same_box.txt
+  python tools/same_box.py $O/eager_kernel_stats.csv $O/headline_runs.txt $O/bench.json > $O/same_box.txt
+  # ... and the same kernels INSIDE the replayed graph (durations and the gap to the next dispatch), same box
+  (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_graph -- python3 $R/bench.py --steps 50 --no-cpu-baseline --no-breakdown --no-train-leg > $O/rocprof_graph.log 2>&1; echo "rocprof(graph) rc=$?")
+  { echo "# the step's kernels inside the replayed HIP graph (last 2000 dispatches of a rocprofv3 --kernel-trace of the headline command, tools/graph_gaps.py):"; python tools/graph_gaps.py $O/prof_graph 2000; } >> $O/same_box.txt
+  cat $O/same_box.txt
   (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --no-cpu-baseline > $O/rocprof_default.log 2>&1; echo "rocprof(default) rc=$?")
   cp $(ls $O/prof_default/*/*_kernel_stats.csv | head -1) $O/default_kernel_stats.csv 2>/dev/null
   i=0
