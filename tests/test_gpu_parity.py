@@ -626,8 +626,11 @@ def test_raster_plan_counts_the_passes(layer, part_tables, W, B, nfar, passes):
     assert (pl["blocks_multi_pass"] > 0) == (passes > 1)
 
 
-@pytest.mark.parametrize("P,VP,W,B", [(1, 64, 24, 3), (5, 300, 40, 9), (17, 1000, 48, 2), (31, 500, 20, 11)])
-def test_seg_custom_part_tables(P, VP, W, B):
+@pytest.mark.parametrize("P,VP,W,B,pvis", [(1, 64, 24, 3, 0.3), (5, 300, 40, 9, 0.3), (17, 1000, 48, 2, 0.3), (31, 500, 20, 11, 0.3),
+                                           # parts of ~2 700 and ~1 300 far-reaching records: each runs through several
+                                           # chunks of the rasteriser's table (started, continued, continued, finished)
+                                           (2, 4200, 48, 3, 1.0), (3, 5000, 64, 2, 0.8)])
+def test_seg_custom_part_tables(P, VP, W, B, pvis):
     """The C ABI takes any part table (P <= 31 parts, each vertex in at most one part, some in none)
     and any vertex count: fewer than 32 output channels, fewer records than a wave's group, batch sizes that do
     not fill the 8-XCD workgroup map, images smaller than one 256-pixel tile.  Forward against the float64
@@ -642,7 +645,7 @@ def test_seg_custom_part_tables(P, VP, W, B):
     ids = [int(v) for v in perm[:off[-1]]]
     pt = ops.build_part_table(ids, off, None, VP, dev())
     proj_np = np.concatenate([rng.uniform(-4.0, W + 4.0, (B, VP, 2)), rng.normal(0, 1, (B, VP, 1))], axis=2)
-    m = rng.choice([1.0, 500.0], size=(B, VP), p=[0.3, 0.7])
+    m = rng.choice([1.0, 500.0], size=(B, VP), p=[pvis, 1.0 - pvis])
     proj, mask = t(proj_np), t(m)
     seg, arg, rec = ops._seg_fwd(proj, mask, W, pt)[:3]
     want = o.projects_to_seg(proj.cpu().numpy().astype(np.float64), m, W, ids, off)
